@@ -1,0 +1,197 @@
+// ec.cuh — short-Weierstrass (a = 0) group arithmetic in extended-Jacobian "XYZZ"
+// coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2), templated over the coordinate field so the
+// same code serves G1 (Fp) and G2 (Fp2).  Bucket accumulation uses the 8M+2S mixed add; the
+// group law is the one ark-ec `short_weierstrass` implements for the reference
+// (cp-groth16/src/prover.rs:86-147), so any sum normalised to affine is bit-identical.
+#pragma once
+#include "field.cuh"
+
+namespace hk {
+
+template <class F>
+struct Affine {
+    F x, y;
+    HK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }   // (0,0) encodes infinity
+    HK_HD static Affine inf() { Affine a; a.x = F::zero(); a.y = F::zero(); return a; }
+};
+
+template <class F>
+struct XYZZ {
+    F x, y, zz, zzz;
+    HK_HD bool is_inf() const { return zz.is_zero(); }
+    HK_HD static XYZZ inf() {
+        XYZZ r; r.x = F::zero(); r.y = F::zero(); r.zz = F::zero(); r.zzz = F::zero();
+        return r;
+    }
+    HK_HD static XYZZ from_affine(const Affine<F>& p) {
+        if (p.is_inf()) return inf();
+        XYZZ r; r.x = p.x; r.y = p.y; r.zz = F::one(); r.zzz = F::one();
+        return r;
+    }
+};
+
+// 2*(x,y) for an affine, non-infinity point ("mdbl-2008-s-1", a = 0)
+template <class F>
+HK_HD XYZZ<F> ec_dbl_affine(const Affine<F>& p) {
+    F u = F::dbl(p.y);
+    F v = F::sqr(u);
+    F w = F::mul(u, v);
+    F s = F::mul(p.x, v);
+    F xx = F::sqr(p.x);
+    F m = F::add(F::dbl(xx), xx);
+    XYZZ<F> r;
+    r.x = F::sub(F::sqr(m), F::dbl(s));
+    r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y));
+    r.zz = v;
+    r.zzz = w;
+    return r;
+}
+
+// 2*P ("dbl-2008-s-1", a = 0)
+template <class F>
+HK_HD XYZZ<F> ec_dbl(const XYZZ<F>& p) {
+    if (p.is_inf()) return p;
+    F u = F::dbl(p.y);
+    F v = F::sqr(u);
+    F w = F::mul(u, v);
+    F s = F::mul(p.x, v);
+    F xx = F::sqr(p.x);
+    F m = F::add(F::dbl(xx), xx);
+    XYZZ<F> r;
+    r.x = F::sub(F::sqr(m), F::dbl(s));
+    r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y));
+    r.zz = F::mul(v, p.zz);
+    r.zzz = F::mul(w, p.zzz);
+    return r;
+}
+
+// acc + affine q  ("madd-2008-s"), all exceptional cases handled
+template <class F>
+HK_HD XYZZ<F> ec_madd(const XYZZ<F>& a, const Affine<F>& q) {
+    if (q.is_inf()) return a;
+    if (a.is_inf()) return XYZZ<F>::from_affine(q);
+    F u2 = F::mul(q.x, a.zz);
+    F s2 = F::mul(q.y, a.zzz);
+    F p = F::sub(u2, a.x);
+    F r = F::sub(s2, a.y);
+    if (p.is_zero()) {
+        if (r.is_zero()) return ec_dbl_affine(q);
+        return XYZZ<F>::inf();
+    }
+    F pp = F::sqr(p);
+    F ppp = F::mul(p, pp);
+    F qq = F::mul(a.x, pp);
+    XYZZ<F> o;
+    o.x = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    o.y = F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(a.y, ppp));
+    o.zz = F::mul(a.zz, pp);
+    o.zzz = F::mul(a.zzz, ppp);
+    return o;
+}
+
+// a + b, both XYZZ ("add-2008-s")
+template <class F>
+HK_HD XYZZ<F> ec_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if (b.is_inf()) return a;
+    if (a.is_inf()) return b;
+    F u1 = F::mul(a.x, b.zz);
+    F u2 = F::mul(b.x, a.zz);
+    F s1 = F::mul(a.y, b.zzz);
+    F s2 = F::mul(b.y, a.zzz);
+    F p = F::sub(u2, u1);
+    F r = F::sub(s2, s1);
+    if (p.is_zero()) {
+        if (r.is_zero()) return ec_dbl(a);
+        return XYZZ<F>::inf();
+    }
+    F pp = F::sqr(p);
+    F ppp = F::mul(p, pp);
+    F qq = F::mul(u1, pp);
+    XYZZ<F> o;
+    o.x = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    o.y = F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(s1, ppp));
+    o.zz = F::mul(F::mul(a.zz, b.zz), pp);
+    o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
+    return o;
+}
+
+template <class F>
+HK_HD Affine<F> ec_neg(const Affine<F>& p) {
+    Affine<F> r; r.x = p.x; r.y = F::neg(p.y);
+    return r;
+}
+template <class F>
+HK_HD XYZZ<F> ec_neg(const XYZZ<F>& p) {
+    XYZZ<F> r = p; r.y = F::neg(p.y);
+    return r;
+}
+
+// k * P for a small unsigned k (bucket-reduction weights)
+template <class F>
+HK_HD XYZZ<F> ec_mul_small(const XYZZ<F>& p, u32 k) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 31; bit >= 0; bit--) {
+        acc = ec_dbl(acc);
+        if ((k >> bit) & 1) acc = ec_add(acc, p);
+    }
+    return acc;
+}
+
+// k * P for a canonical (non-Montgomery) multi-limb scalar, MSB-first double-and-add
+template <class F, int NL>
+HK_HD XYZZ<F> ec_mul_limbs(const XYZZ<F>& p, const u32 (&k)[NL]) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = NL - 1; i >= 0; i--) {
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = ec_dbl(acc);
+            if ((k[i] >> bit) & 1) acc = ec_add(acc, p);
+        }
+    }
+    return acc;
+}
+
+// ---- inversion (Fermat) and normalisation to affine -----------------------------------------
+template <class P>
+HK_HD Fp<P> fp_inv(const Fp<P>& a) {
+    // a^(p-2); exponent limbs = modulus - 2 with borrow propagation
+    u32 ex[P::N];
+    u32 borrow = 2;
+    for (int i = 0; i < P::N; i++) {
+        u32 m = P::MOD[i];
+        ex[i] = m - borrow;
+        borrow = (m < borrow) ? 1u : 0u;
+    }
+    Fp<P> result = Fp<P>::one();
+    for (int i = P::N - 1; i >= 0; i--) {
+        u32 e = ex[i];
+        for (int bit = 31; bit >= 0; bit--) {
+            result = Fp<P>::sqr(result);
+            if ((e >> bit) & 1) result = Fp<P>::mul(result, a);
+        }
+    }
+    return result;
+}
+template <class P>
+HK_HD Fp2<P> fp_inv(const Fp2<P>& a) {
+    typedef Fp<P> B;
+    B n = B::add(B::sqr(a.c0), B::sqr(a.c1));
+    B ni = fp_inv(n);
+    Fp2<P> r;
+    r.c0 = B::mul(a.c0, ni);
+    r.c1 = B::neg(B::mul(a.c1, ni));
+    return r;
+}
+
+template <class F>
+HK_HD Affine<F> ec_to_affine(const XYZZ<F>& p) {
+    if (p.is_inf()) return Affine<F>::inf();
+    // 1/zzz, then 1/zz = zzz^-2 * zz^2  (zz^3 = zzz^2  =>  zz^-1 = zz^2 / zzz^2)
+    F zzz_inv = fp_inv(p.zzz);
+    F zz_inv = F::mul(F::sqr(zzz_inv), F::sqr(p.zz));
+    Affine<F> r;
+    r.x = F::mul(p.x, zz_inv);
+    r.y = F::mul(p.y, zzz_inv);
+    return r;
+}
+
+}  // namespace hk

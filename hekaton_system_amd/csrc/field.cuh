@@ -1,0 +1,208 @@
+// field.cuh — Montgomery prime-field and quadratic-extension arithmetic on 32-bit limbs,
+// written for CDNA4 VALU (v_mad_u64_u32 + v_add_co/v_addc chains); all loops fully unrolled
+// so the modulus limbs fold into instruction immediates and every element lives in VGPRs.
+//
+// Memory form == ark-ff `Fp<MontBackend<_,N64>>` (R = 2^(64*N64) = 2^(32*N)), so buffers cross
+// the C ABI without conversion.  Also compiles as plain host C++ (tests build it with g++ to
+// unit-test the arithmetic against tests/golden without a GPU; the library itself never runs it
+// on the CPU).
+#pragma once
+#include <stdint.h>
+#include "hk_params.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HK_HD __host__ __device__ __forceinline__
+#define HK_UNROLL _Pragma("unroll")
+#else
+#define HK_HD inline
+#define HK_UNROLL
+#endif
+
+namespace hk {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---- parameter packs ---------------------------------------------------------------------
+#define HK_DEFINE_FIELD(NAME, PREFIX)                                        \
+    struct NAME {                                                            \
+        static constexpr int N = PREFIX##_N;                                 \
+        static constexpr u32 MOD[PREFIX##_N] = PREFIX##_MOD;                 \
+        static constexpr u32 ONE[PREFIX##_N] = PREFIX##_ONE;                 \
+        static constexpr u32 R2[PREFIX##_N] = PREFIX##_R2;                   \
+        static constexpr u32 INV = PREFIX##_INV32;                           \
+    };
+
+HK_DEFINE_FIELD(Bn254FrP, HK_BN254_FR)
+HK_DEFINE_FIELD(Bn254FqP, HK_BN254_FQ)
+HK_DEFINE_FIELD(Bls381FrP, HK_BLS12_381_FR)
+HK_DEFINE_FIELD(Bls381FqP, HK_BLS12_381_FQ)
+
+// ---- prime field ---------------------------------------------------------------------------
+template <class P>
+struct Fp {
+    static constexpr int N = P::N;
+    typedef P Params;
+    u32 v[N];
+
+    HK_HD static Fp zero() {
+        Fp r;
+        HK_UNROLL for (int i = 0; i < N; i++) r.v[i] = 0;
+        return r;
+    }
+    HK_HD static Fp one() {
+        Fp r;
+        HK_UNROLL for (int i = 0; i < N; i++) r.v[i] = P::ONE[i];
+        return r;
+    }
+    HK_HD static Fp r2() {
+        Fp r;
+        HK_UNROLL for (int i = 0; i < N; i++) r.v[i] = P::R2[i];
+        return r;
+    }
+    HK_HD bool is_zero() const {
+        u32 acc = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) acc |= v[i];
+        return acc == 0;
+    }
+    HK_HD bool operator==(const Fp& o) const {
+        u32 acc = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) acc |= (v[i] ^ o.v[i]);
+        return acc == 0;
+    }
+    HK_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+
+    // r = a - MOD if a >= MOD (a < 2*MOD, carry-free because MOD has a spare top bit)
+    HK_HD static Fp reduce_once(const Fp& a) {
+        Fp s;
+        u64 borrow = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            u64 d = (u64)a.v[i] - P::MOD[i] - borrow;
+            s.v[i] = (u32)d;
+            borrow = (d >> 32) & 1;
+        }
+        Fp r;
+        HK_UNROLL for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : s.v[i];
+        return r;
+    }
+
+    HK_HD static Fp add(const Fp& a, const Fp& b) {
+        Fp t;
+        u64 c = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            c += (u64)a.v[i] + b.v[i];
+            t.v[i] = (u32)c;
+            c >>= 32;
+        }
+        return reduce_once(t);   // a + b < 2*MOD < 2^(32N)
+    }
+    HK_HD static Fp dbl(const Fp& a) { return add(a, a); }
+
+    HK_HD static Fp sub(const Fp& a, const Fp& b) {
+        Fp t;
+        u64 borrow = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            u64 d = (u64)a.v[i] - b.v[i] - borrow;
+            t.v[i] = (u32)d;
+            borrow = (d >> 32) & 1;
+        }
+        // add MOD back when we borrowed
+        u32 mask = (u32)0 - (u32)borrow;
+        u64 c = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            c += (u64)t.v[i] + (P::MOD[i] & mask);
+            t.v[i] = (u32)c;
+            c >>= 32;
+        }
+        return t;
+    }
+    HK_HD static Fp neg(const Fp& a) {
+        if (a.is_zero()) return a;
+        Fp t;
+        u64 borrow = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            u64 d = (u64)P::MOD[i] - a.v[i] - borrow;
+            t.v[i] = (u32)d;
+            borrow = (d >> 32) & 1;
+        }
+        return t;
+    }
+
+    // CIOS Montgomery product, one 32-bit word of b per round.  MOD < 2^(32N-1) keeps the
+    // running value below 2*MOD, so N+1 words suffice and the top word is 0 after each round.
+    HK_HD static Fp mul(const Fp& a, const Fp& b) {
+        u32 t[N + 1];
+        HK_UNROLL for (int i = 0; i <= N; i++) t[i] = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            u64 c = 0;
+            HK_UNROLL for (int j = 0; j < N; j++) {
+                c = (u64)a.v[j] * b.v[i] + t[j] + c;
+                t[j] = (u32)c;
+                c >>= 32;
+            }
+            c += t[N];
+            t[N] = (u32)c;
+            u32 m = t[0] * P::INV;
+            c = (u64)m * P::MOD[0] + t[0];
+            c >>= 32;
+            HK_UNROLL for (int j = 1; j < N; j++) {
+                c = (u64)m * P::MOD[j] + t[j] + c;
+                t[j - 1] = (u32)c;
+                c >>= 32;
+            }
+            c += t[N];
+            t[N - 1] = (u32)c;
+            t[N] = (u32)(c >> 32);
+        }
+        Fp r;
+        HK_UNROLL for (int i = 0; i < N; i++) r.v[i] = t[i];
+        return reduce_once(r);
+    }
+    HK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
+
+    // canonical integer -> Montgomery, Montgomery -> canonical
+    HK_HD static Fp to_mont(const Fp& a) { return mul(a, r2()); }
+    HK_HD static Fp from_mont(const Fp& a) {
+        Fp o = zero();
+        o.v[0] = 1;
+        return mul(a, o);
+    }
+};
+
+// ---- Fq2 = Fq[u]/(u^2+1) (both BN254 and BLS12-381 towers) -------------------------------------
+template <class P>
+struct Fp2 {
+    typedef Fp<P> B;
+    typedef P Params;
+    static constexpr int N = 2 * P::N;
+    B c0, c1;
+
+    HK_HD static Fp2 zero() { Fp2 r; r.c0 = B::zero(); r.c1 = B::zero(); return r; }
+    HK_HD static Fp2 one() { Fp2 r; r.c0 = B::one(); r.c1 = B::zero(); return r; }
+    HK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    HK_HD bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
+    HK_HD bool operator!=(const Fp2& o) const { return !(*this == o); }
+    HK_HD static Fp2 add(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = B::add(a.c0, b.c0); r.c1 = B::add(a.c1, b.c1); return r; }
+    HK_HD static Fp2 sub(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = B::sub(a.c0, b.c0); r.c1 = B::sub(a.c1, b.c1); return r; }
+    HK_HD static Fp2 dbl(const Fp2& a) { return add(a, a); }
+    HK_HD static Fp2 neg(const Fp2& a) { Fp2 r; r.c0 = B::neg(a.c0); r.c1 = B::neg(a.c1); return r; }
+    HK_HD static Fp2 mul(const Fp2& a, const Fp2& b) {       // Karatsuba, 3 base muls
+        B v0 = B::mul(a.c0, b.c0);
+        B v1 = B::mul(a.c1, b.c1);
+        B s = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        Fp2 r;
+        r.c0 = B::sub(v0, v1);
+        r.c1 = B::sub(B::sub(s, v0), v1);
+        return r;
+    }
+    HK_HD static Fp2 sqr(const Fp2& a) {                     // (a0+a1)(a0-a1), 2 a0 a1
+        B t = B::mul(a.c0, a.c1);
+        Fp2 r;
+        r.c0 = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
+        r.c1 = B::dbl(t);
+        return r;
+    }
+};
+
+}  // namespace hk

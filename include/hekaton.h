@@ -1,0 +1,175 @@
+/*
+ * hekaton.h — C ABI of the MI355X-native Hekaton subcircuit prover (libhekaton.so).
+ *
+ * This is the drop-in boundary for ONE hot path of zhaowenlan1779/hekaton-system:
+ * the per-subcircuit CP-Groth16 commit + prove step.  The reference has no FFI
+ * (SURVEY.md F5); the entry points below are what a Rust shim binds to replace
+ * the arkworks call sites of that path (the binding is shown in INTEGRATION.md).
+ * Every entry point cites the reference interface it replaces (paths relative to
+ * the reference repository root).
+ *
+ * Conventions
+ *   - Field elements are little-endian limb arrays in MONTGOMERY form with
+ *     R = 2^(64*N), exactly the in-memory form of ark-ff `Fp<MontBackend<_,N>>`
+ *     (N = 4 for BN254 Fr/Fq and BLS12-381 Fr; N = 6 for BLS12-381 Fq), unless a
+ *     parameter says "canonical" (ark `BigInt<N>`: plain integer, LE limbs).
+ *   - G1 affine = x || y ; G2 affine = x.c0 || x.c1 || y.c0 || y.c1 ; the point at
+ *     infinity is encoded as all-zero coordinates ((0,0) is on neither curve).
+ *     Rust `Affine<P>{x,y,infinity}` is not repr(C): the shim repacks once at
+ *     key-load time.
+ *   - Pointers marked [h|d] may be host or device memory (detected with
+ *     hipPointerGetAttributes); [h] must be host, [d] must be device.
+ *   - All calls are thread-safe on a shared hk_ctx: each call runs on a private
+ *     lane (HIP stream + scratch arena), mirroring `compute_responses`
+ *     (mpi-snark/src/bin/node.rs:745-795) which proves from several OS threads.
+ *   - There is NO CPU backend: hk_ctx_create fails with HK_ERR_DEVICE when no
+ *     gfx950 device is usable.  Randomness (r, s, kappa) always comes from the
+ *     caller (prover.rs:28-29, committer.rs:85); the library is deterministic.
+ */
+#ifndef HEKATON_H
+#define HEKATON_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hk_ctx hk_ctx;   /* one per (process, device): lanes, twiddles, scratch */
+typedef struct hk_pk hk_pk;     /* device-resident proving-key class (+ its R1CS matrices) */
+
+typedef enum { HK_BN254 = 0, HK_BLS12_381 = 1 } hk_curve;
+
+typedef enum {
+    HK_OK = 0,
+    HK_ERR_LEN = 1,               /* ark `msm` Err(min_len) on length mismatch   */
+    HK_ERR_DOMAIN_TOO_LARGE = 2,  /* SynthesisError::PolynomialDegreeTooLarge                 */
+    HK_ERR_DEVICE = 3,            /* no device / HIP runtime error                            */
+    HK_ERR_ARG = 4,
+    HK_ERR_NOMEM = 5
+} hk_status;
+
+/* One R1CS matrix in CSR form; mirrors one of ark_relations `ConstraintMatrices::{a,b,c}`
+ * (Vec<Vec<(F, usize)>>): row i holds (val, col) pairs, col indexes instance||witness. */
+typedef struct {
+    const uint64_t* row_ptr;   /* [n_rows + 1]                 [h|d] */
+    const uint32_t* col;       /* [nnz]                        [h|d] */
+    const void*     val_mont;  /* [nnz] Fr, Montgomery         [h|d] */
+    size_t n_rows;
+    size_t nnz;
+} hk_csr;
+
+/* Everything `ProvingKey<E>` (cp-groth16/src/data_structures.rs:66-83) holds that the
+ * prover touches, plus the circuit class's constraint matrices (identical for every
+ * subcircuit of a class, so uploaded once with the key). All arrays [h|d], packed affine. */
+typedef struct {
+    const void* a_g;  size_t a_len;        /* pk.a_g   : n_v G1  (data_structures.rs:72) */
+    const void* b_g;  size_t b_g_len;      /* pk.b_g   : n_v G1  (:74)                   */
+    const void* b_h;  size_t b_h_len;      /* pk.b_h   : n_v G2  (:76)                   */
+    const void* h_g;  size_t h_len;        /* pk.h_g   : m-1 G1  (:78)                   */
+    const void* const* ck_stage;           /* pk.ck.deltas_abc_g[stage] (:113)           */
+    const size_t* ck_len;
+    size_t n_stages;
+    const void* deltas_g;                  /* pk.deltas_g : n_stages G1 (:82)            */
+    const void* last_delta_h;              /* pk.vk.deltas_h.last() : 1 G2 (:95-97)      */
+    const void* alpha_g;                   /* pk.vk.alpha_g : 1 G1 (:36)                 */
+    const void* beta_g;                    /* pk.beta_g : 1 G1 (:70)                     */
+    const void* beta_h;                    /* pk.vk.beta_h : 1 G2 (:38)                  */
+    const hk_csr* A; const hk_csr* B; const hk_csr* C;   /* may be NULL: then hk_prove is unavailable */
+    size_t n_inst;                         /* cs.num_instance_variables()                */
+    size_t n_constraints;                  /* cs.num_constraints()                       */
+} hk_pk_desc;
+
+/* Per-phase device timings of the last hk_prove / hk_commit on the calling thread's lane,
+ * measured with HIP events on the lane's stream (milliseconds). Replaces the reference's
+ * start_timer!/end_timer! brackets (cp-groth16/src/prover.rs:65-150). */
+typedef struct {
+    float total_ms;
+    float digits_ms;       /* scalar from-Montgomery + signed-digit split + bucket sort   */
+    float msm_a_ms;        /* "Compute A"        prover.rs:85-90   */
+    float msm_b_g1_ms;     /* "Compute B in G1"  prover.rs:95-100  */
+    float msm_b_g2_ms;     /* "Compute B in G2"  prover.rs:105-108 */
+    float msm_l_ms;        /* "Compute L"        prover.rs:113-118 */
+    float witness_map_ms;  /* "R1CS to QAP witness map" prover.rs:122-125 */
+    float msm_h_ms;        /* "Compute H"        prover.rs:127-130 */
+    float finish_ms;       /* "Finish C" + into_affine prover.rs:135-155, committer.rs:112-114 */
+    float accum_kernel_ms; /* sum of the bucket-accumulate kernel launches (dominant kernel) */
+    uint32_t accum_kernel_launches;
+} hk_timings;
+
+const char* hk_status_str(hk_status s);
+const char* hk_version(void);
+
+/* ---- context ------------------------------------------------------------------------ */
+hk_status hk_ctx_create(hk_curve curve, int device_id, hk_ctx** out);
+void      hk_ctx_destroy(hk_ctx* ctx);
+hk_status hk_ctx_sync(hk_ctx* ctx);                      /* drain every lane */
+hk_status hk_ctx_set_profiling(hk_ctx* ctx, int enable); /* record hk_timings per call */
+hk_status hk_ctx_last_timings(hk_ctx* ctx, hk_timings* out);
+/* element sizes for this curve: Fr, Fq, G1 affine, G2 affine bytes */
+hk_status hk_ctx_sizes(const hk_ctx* ctx, size_t* fr, size_t* fq, size_t* g1, size_t* g2);
+
+/* device-memory plumbing so a host (Rust shim, ctypes) can keep inputs resident */
+hk_status hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr);
+hk_status hk_dev_free(hk_ctx* ctx, void* dptr);
+hk_status hk_dev_upload(hk_ctx* ctx, void* dst_d, const void* src_h, size_t bytes);
+hk_status hk_dev_download(hk_ctx* ctx, void* dst_h, const void* src_d, size_t bytes);
+
+/* ---- primitives: one per arkworks call the hot path makes ----------------------------- */
+
+/* VariableBaseMSM for G1 — replaces `G::Group::msm_bigint(&query[1..], assignment)`
+ * (cp-groth16/src/prover.rs:167, scalars canonical BigInt) and `E::G1::msm(bases, scalars)`
+ * (prover.rs:117,129; committer.rs:89, scalars Montgomery Fr) and `msm_unchecked`
+ * (committer.rs:113).  checked != 0: HK_ERR_LEN when n_bases != n_scalars (ark `msm`);
+ * checked == 0: zip to min(n_bases, n_scalars) (ark `msm_unchecked` / `msm_bigint`).
+ * out_affine [h]: packed affine sum (infinity = zeros). */
+hk_status hk_msm_g1(hk_ctx* ctx, const void* bases, size_t n_bases,
+                    const void* scalars, size_t n_scalars,
+                    int scalars_are_montgomery, int checked, void* out_affine);
+/* Same for G2 — replaces prover.rs:107 (`calculate_coeff` over pk.b_h). */
+hk_status hk_msm_g2(hk_ctx* ctx, const void* bases, size_t n_bases,
+                    const void* scalars, size_t n_scalars,
+                    int scalars_are_montgomery, int checked, void* out_affine);
+
+/* ark-poly Radix2EvaluationDomain {fft,ifft}_in_place and the coset forms with shift
+ * F::GENERATOR.  data [h|d]: 2^log_m Fr (Montgomery), natural order in
+ * and out.  HK_ERR_DOMAIN_TOO_LARGE when log_m > TWO_ADICITY. */
+hk_status hk_ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int coset);
+
+/* R1CSToQAP::witness_map (LibsnarkReduction) — replaces `cs.map(QAP::witness_map::<_, D<_>>)`
+ * at cp-groth16/src/prover.rs:123.  z_mont: full assignment instance||witness (n_v Fr).
+ * h_out [h|d]: m Fr (Montgomery), natural order; *m_out = domain size. */
+hk_status hk_witness_map(hk_ctx* ctx, const hk_csr* A, const hk_csr* B, const hk_csr* C,
+                         size_t n_inst, size_t n_constraints,
+                         const void* z_mont, size_t n_v,
+                         void* h_out, size_t h_capacity, size_t* m_out);
+
+/* ---- proving-key residency -------------------------------------------------------------- */
+hk_status hk_pk_upload(hk_ctx* ctx, const hk_pk_desc* desc, hk_pk** out);
+void      hk_pk_free(hk_pk* pk);
+
+/* ---- fused per-subcircuit calls (the unit of work the metric counts) --------------------- */
+
+/* CommitmentBuilder::commit arithmetic (cp-groth16/src/committer.rs:87-91):
+ * com = msm(ck[stage], w_stage) + kappa * last_delta_g.  w_stage_mont [h|d]: n Fr; HK_ERR_LEN
+ * unless n == ck_len[stage] (committer.rs:83 assert). com_affine_out [h]. */
+hk_status hk_commit(hk_ctx* ctx, const hk_pk* pk, size_t stage,
+                    const void* w_stage_mont, size_t n, const void* kappa_mont,
+                    void* com_affine_out);
+
+/* CPGroth16::prove_last_stage (prover.rs:78-155) followed by CommitmentBuilder::prove's
+ * kappa correction (committer.rs:112-114), everything after constraint synthesis:
+ *   z_mont [h|d]  full assignment instance||witness, n_v Fr Montgomery, z[0] = 1
+ *   r_mont,s_mont [h] the two blinders (prover.rs:28-29)
+ *   kappas_mont [h]   n_kappas = n_stages-1 commitment randomizers (committer.rs:110-113)
+ * Outputs [h]: proof.a (G1), proof.b (G2), proof.c (G1), packed affine. */
+hk_status hk_prove(hk_ctx* ctx, const hk_pk* pk, const void* z_mont, size_t n_v,
+                   const void* r_mont, const void* s_mont,
+                   const void* kappas_mont, size_t n_kappas,
+                   void* proof_a_g1, void* proof_b_g2, void* proof_c_g1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEKATON_H */
