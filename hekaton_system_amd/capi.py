@@ -1,0 +1,306 @@
+"""ctypes binding of include/hekaton.h (libhekaton.so) — the only door into the HIP kernels.
+
+There is no CPU path: importing works anywhere (so host logic can be tested), but creating a
+`Context` without a gfx950 device raises, and a missing libhekaton.so raises at load time.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhekaton.so")
+
+HK_BN254, HK_BLS12_381 = 0, 1
+HK_OK, HK_ERR_LEN, HK_ERR_DOMAIN_TOO_LARGE, HK_ERR_DEVICE, HK_ERR_ARG, HK_ERR_NOMEM = range(6)
+CURVE_IDS = {"bn254": HK_BN254, "bls12_381": HK_BLS12_381}
+
+
+class HekatonError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__("%s failed: %s" % (what, status_str(status)))
+
+
+class hk_csr(C.Structure):
+    _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("val_mont", C.c_void_p),
+                ("n_rows", C.c_size_t), ("nnz", C.c_size_t)]
+
+
+class hk_pk_desc(C.Structure):
+    _fields_ = [("a_g", C.c_void_p), ("a_len", C.c_size_t),
+                ("b_g", C.c_void_p), ("b_g_len", C.c_size_t),
+                ("b_h", C.c_void_p), ("b_h_len", C.c_size_t),
+                ("h_g", C.c_void_p), ("h_len", C.c_size_t),
+                ("ck_stage", C.POINTER(C.c_void_p)), ("ck_len", C.POINTER(C.c_size_t)),
+                ("n_stages", C.c_size_t),
+                ("deltas_g", C.c_void_p), ("last_delta_h", C.c_void_p),
+                ("alpha_g", C.c_void_p), ("beta_g", C.c_void_p), ("beta_h", C.c_void_p),
+                ("A", C.POINTER(hk_csr)), ("B", C.POINTER(hk_csr)), ("C", C.POINTER(hk_csr)),
+                ("n_inst", C.c_size_t), ("n_constraints", C.c_size_t)]
+
+
+class hk_timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("total_ms", "digits_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "msm_l_ms",
+                 "witness_map_ms", "msm_h_ms", "finish_ms", "accum_kernel_ms")] + \
+               [("accum_kernel_launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/hekaton.h declares (tests check the library exports all of them)
+EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk_ctx_sync",
+           "hk_ctx_set_profiling", "hk_ctx_last_timings", "hk_ctx_sizes", "hk_dev_alloc", "hk_dev_free",
+           "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
+           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove"]
+
+_lib = None
+
+
+def load():
+    """Loads libhekaton.so (built by __graft_entry__.build()); fails loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libhekaton.so not built (%s): run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` — there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    lib.hk_status_str.restype = C.c_char_p
+    lib.hk_status_str.argtypes = [i]
+    lib.hk_version.restype = C.c_char_p
+    lib.hk_ctx_create.argtypes = [i, i, C.POINTER(vp)]
+    lib.hk_ctx_destroy.argtypes = [vp]
+    lib.hk_ctx_destroy.restype = None
+    lib.hk_ctx_sync.argtypes = [vp]
+    lib.hk_ctx_set_profiling.argtypes = [vp, i]
+    lib.hk_ctx_last_timings.argtypes = [vp, C.POINTER(hk_timings)]
+    lib.hk_ctx_sizes.argtypes = [vp] + [C.POINTER(sz)] * 4
+    lib.hk_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.hk_dev_free.argtypes = [vp, vp]
+    lib.hk_dev_upload.argtypes = [vp, vp, vp, sz]
+    lib.hk_dev_download.argtypes = [vp, vp, vp, sz]
+    for f in (lib.hk_msm_g1, lib.hk_msm_g2):
+        f.argtypes = [vp, vp, sz, vp, sz, i, i, vp]
+    lib.hk_ntt.argtypes = [vp, vp, C.c_uint, i, i]
+    lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
+                                   vp, sz, vp, sz, C.POINTER(sz)]
+    lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
+    lib.hk_pk_free.argtypes = [vp]
+    lib.hk_pk_free.restype = None
+    lib.hk_commit.argtypes = [vp, vp, sz, vp, sz, vp, vp]
+    lib.hk_prove.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def status_str(s):
+    return load().hk_status_str(int(s)).decode()
+
+
+def check(status, what):
+    if status != HK_OK:
+        raise HekatonError(status, what)
+
+
+def ptr(x):
+    """c_void_p of a numpy array / DeviceBuffer / bytes-like / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return C.c_void_p(x.ptr)
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return C.c_void_p(x.ctypes.data)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    raise TypeError(type(x))
+
+
+class DeviceBuffer:
+    """HBM allocation owned through the C ABI (hk_dev_alloc/free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(load().hk_dev_alloc(ctx.handle, self.nbytes, C.byref(p)), "hk_dev_alloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(ctx, arr.nbytes)
+        check(load().hk_dev_upload(ctx.handle, buf.ptr, arr.ctypes.data, arr.nbytes), "hk_dev_upload")
+        return buf
+
+    def to_host(self):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        check(load().hk_dev_download(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes),
+              "hk_dev_download")
+        return out
+
+    def free(self):
+        if self.ptr:
+            load().hk_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """hk_ctx wrapper: one per (process, device)."""
+
+    def __init__(self, curve="bn254", device=0):
+        self.lib = load()
+        self.curve = curve
+        h = C.c_void_p()
+        check(self.lib.hk_ctx_create(CURVE_IDS[curve], int(device), C.byref(h)), "hk_ctx_create")
+        self.handle = h
+        fr, fq, g1, g2 = (C.c_size_t() for _ in range(4))
+        check(self.lib.hk_ctx_sizes(h, C.byref(fr), C.byref(fq), C.byref(g1), C.byref(g2)), "hk_ctx_sizes")
+        self.fr_bytes, self.fq_bytes, self.g1_bytes, self.g2_bytes = fr.value, fq.value, g1.value, g2.value
+
+    def close(self):
+        if self.handle:
+            self.lib.hk_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        check(self.lib.hk_ctx_sync(self.handle), "hk_ctx_sync")
+
+    def set_profiling(self, on=True):
+        check(self.lib.hk_ctx_set_profiling(self.handle, int(bool(on))), "hk_ctx_set_profiling")
+
+    def last_timings(self):
+        t = hk_timings()
+        check(self.lib.hk_ctx_last_timings(self.handle, C.byref(t)), "hk_ctx_last_timings")
+        return t.as_dict()
+
+    # ---- primitives ---------------------------------------------------------------------------
+    def _msm(self, fn, nbytes, bases, n_bases, scalars, n_scalars, mont, checked):
+        out = np.zeros(nbytes, dtype=np.uint8)
+        check(fn(self.handle, ptr(bases), n_bases, ptr(scalars), n_scalars, int(mont), int(checked),
+                 out.ctypes.data), fn.__name__)
+        return out
+
+    def msm_g1(self, bases, scalars, n_bases=None, n_scalars=None, montgomery=True, checked=True):
+        """E::G1::msm / msm_bigint / msm_unchecked (prover.rs:88,97,117,129; committer.rs:89,113)."""
+        nb = n_bases if n_bases is not None else len(bases) // self.g1_bytes
+        ns = n_scalars if n_scalars is not None else len(scalars) // self.fr_bytes
+        return self._msm(self.lib.hk_msm_g1, self.g1_bytes, bases, nb, scalars, ns, montgomery, checked)
+
+    def msm_g2(self, bases, scalars, n_bases=None, n_scalars=None, montgomery=True, checked=True):
+        """E::G2 MSM (prover.rs:107)."""
+        nb = n_bases if n_bases is not None else len(bases) // self.g2_bytes
+        ns = n_scalars if n_scalars is not None else len(scalars) // self.fr_bytes
+        return self._msm(self.lib.hk_msm_g2, self.g2_bytes, bases, nb, scalars, ns, montgomery, checked)
+
+    def ntt(self, data, log_m, inverse=False, coset=False):
+        """In-place on `data` (numpy uint8 array of 2^log_m Fr or a DeviceBuffer)."""
+        check(self.lib.hk_ntt(self.handle, ptr(data), int(log_m), int(inverse), int(coset)), "hk_ntt")
+        return data
+
+    def witness_map(self, A, B, Cm, n_inst, n_constraints, z, n_v=None):
+        """R1CSToQAP::witness_map (prover.rs:123).  A/B/Cm: (row_ptr u64, col u32, val bytes) triples.
+        Returns (h bytes [m Fr, natural order], m)."""
+        keep = []
+        csrs = []
+        for (rp, col, val) in (A, B, Cm):
+            rp = np.ascontiguousarray(rp, dtype=np.uint64)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            val = np.ascontiguousarray(val, dtype=np.uint8)
+            keep += [rp, col, val]
+            csrs.append(hk_csr(rp.ctypes.data, col.ctypes.data, val.ctypes.data, len(rp) - 1, len(col)))
+        nv = n_v if n_v is not None else len(z) // self.fr_bytes
+        m = 1
+        while m < n_constraints + n_inst:
+            m *= 2
+        out = np.zeros(m * self.fr_bytes, dtype=np.uint8)
+        m_out = C.c_size_t()
+        check(self.lib.hk_witness_map(self.handle, C.byref(csrs[0]), C.byref(csrs[1]), C.byref(csrs[2]),
+                                      n_inst, n_constraints, ptr(z), nv, out.ctypes.data, m, C.byref(m_out)),
+              "hk_witness_map")
+        return out, m_out.value
+
+    def pk_upload(self, *, a_g, b_g, b_h, h_g, ck_stages, deltas_g, last_delta_h, alpha_g, beta_g, beta_h,
+                  matrices=None, n_inst=0, n_constraints=0):
+        """hk_pk_upload: all arguments packed-affine numpy uint8 arrays (or DeviceBuffers with explicit
+        lengths via (buf, n) tuples).  matrices = (A, B, C) CSR triples as in witness_map."""
+        def arr(x):
+            return np.ascontiguousarray(x, dtype=np.uint8)
+        keep = []
+        d = hk_pk_desc()
+        a_g, b_g, b_h, h_g = arr(a_g), arr(b_g), arr(b_h), arr(h_g)
+        keep += [a_g, b_g, b_h, h_g]
+        d.a_g, d.a_len = a_g.ctypes.data, len(a_g) // self.g1_bytes
+        d.b_g, d.b_g_len = b_g.ctypes.data, len(b_g) // self.g1_bytes
+        d.b_h, d.b_h_len = b_h.ctypes.data, len(b_h) // self.g2_bytes
+        d.h_g, d.h_len = h_g.ctypes.data, len(h_g) // self.g1_bytes
+        cks = [arr(c) for c in ck_stages]
+        keep += cks
+        ck_ptrs = (C.c_void_p * len(cks))(*[c.ctypes.data for c in cks])
+        ck_lens = (C.c_size_t * len(cks))(*[len(c) // self.g1_bytes for c in cks])
+        d.ck_stage, d.ck_len, d.n_stages = ck_ptrs, ck_lens, len(cks)
+        small = [arr(x) for x in (deltas_g, last_delta_h, alpha_g, beta_g, beta_h)]
+        keep += small
+        d.deltas_g, d.last_delta_h, d.alpha_g, d.beta_g, d.beta_h = [s.ctypes.data for s in small]
+        csrs = []
+        if matrices is not None:
+            for (rp, col, val) in matrices:
+                rp = np.ascontiguousarray(rp, dtype=np.uint64)
+                col = np.ascontiguousarray(col, dtype=np.uint32)
+                val = arr(val)
+                keep += [rp, col, val]
+                csrs.append(hk_csr(rp.ctypes.data, col.ctypes.data, val.ctypes.data, len(rp) - 1, len(col)))
+            d.A, d.B, d.C = C.pointer(csrs[0]), C.pointer(csrs[1]), C.pointer(csrs[2])
+        d.n_inst, d.n_constraints = n_inst, n_constraints
+        h = C.c_void_p()
+        check(self.lib.hk_pk_upload(self.handle, C.byref(d), C.byref(h)), "hk_pk_upload")
+        return DevicePk(self, h)
+
+
+class DevicePk:
+    """hk_pk wrapper: a proving-key class resident in HBM (with its shift tables and matrices)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.handle = handle
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.hk_pk_free(self.handle)
+            self.handle = None
+
+    def commit(self, stage, w_stage, kappa, n=None):
+        """committer.rs:87-91 — msm(ck[stage], w) + kappa * last_delta_g; returns packed G1 bytes."""
+        ctx = self.ctx
+        n = n if n is not None else len(w_stage) // ctx.fr_bytes
+        kappa = np.ascontiguousarray(kappa, dtype=np.uint8)
+        out = np.zeros(ctx.g1_bytes, dtype=np.uint8)
+        check(ctx.lib.hk_commit(ctx.handle, self.handle, stage, ptr(w_stage) if n else None, n,
+                                kappa.ctypes.data, out.ctypes.data), "hk_commit")
+        return out
+
+    def prove(self, z, r, s, kappas, n_v=None):
+        """prover.rs:78-155 + committer.rs:112-114; returns (a, b, c) packed affine bytes."""
+        ctx = self.ctx
+        n_v = n_v if n_v is not None else len(z) // ctx.fr_bytes
+        r = np.ascontiguousarray(r, dtype=np.uint8)
+        s = np.ascontiguousarray(s, dtype=np.uint8)
+        kap = np.ascontiguousarray(kappas, dtype=np.uint8)
+        nk = len(kap) // ctx.fr_bytes
+        a = np.zeros(ctx.g1_bytes, dtype=np.uint8)
+        b = np.zeros(ctx.g2_bytes, dtype=np.uint8)
+        c = np.zeros(ctx.g1_bytes, dtype=np.uint8)
+        check(ctx.lib.hk_prove(ctx.handle, self.handle, ptr(z), n_v, r.ctypes.data, s.ctypes.data,
+                               kap.ctypes.data if nk else None, nk, a.ctypes.data, b.ctypes.data,
+                               c.ctypes.data), "hk_prove")
+        return a, b, c

@@ -1,0 +1,113 @@
+// curve_ops_impl.cuh — per-curve host orchestration (templated on the curve traits); included by
+// hk_<curve>_ops.hip.  Heavy kernels are instantiated in their own translation units
+// (hk_<curve>_{g1,g2,fr}.hip) and referenced here through extern templates.
+#pragma once
+#include "msm_driver.cuh"
+
+namespace hk {
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+inline size_t msm_sort_bytes(const MsmPlan& p) {
+    return al256(4ull * p.NB) * 2 + al256(4ull * (p.NB + 1)) + al256(4ull * ((size_t)p.n * p.W + 1)) + 1024;
+}
+template <class F>
+inline size_t msm_run_bytes(const MsmPlan& p) {
+    size_t n0 = 2ull * p.T[0], n1 = p.n_levels > 1 ? 2ull * p.T[1] : 2;
+    return al256(sizeof(XYZZ<F>) * p.NB) + al256(4 * n0) + al256(sizeof(XYZZ<F>) * n0) + al256(4 * n1) +
+           al256(sizeof(XYZZ<F>) * n1) + al256(sizeof(XYZZ<F>) * p.WP * (p.B / p.K)) +
+           al256(sizeof(XYZZ<F>) * p.WP) + 2048;
+}
+
+// window size for an MSM over caller-supplied bases (no shift tables: all W windows keep their own
+// buckets, W * 2^(c-1) counters must fit the 128 KiB LDS histogram)
+inline u32 msm_pick_c_plain(size_t n, u32 fr_bits) {
+    u32 best = 4;
+    double best_cost = 1e300;
+    for (u32 c = 3; c <= 12; c++) {
+        u32 W = (fr_bits + 2 + c - 1) / c;
+        u64 NB = (u64)W << (c - 1);
+        if (NB > (u64)MSM_LDS_COUNTERS) continue;
+        double cost = (double)n * W + 4.0 * (double)NB;
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+// window size when shift tables make every window share one bucket set (WP = 1)
+inline u32 msm_pick_c_tables(size_t n, u32 fr_bits) {
+    u32 best = 6;
+    double best_cost = 1e300;
+    for (u32 c = 5; c <= 16; c++) {
+        u32 W = (fr_bits + 2 + c - 1) / c;
+        double cost = (double)n * W + 6.0 * (double)(1u << (c - 1));
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+template <class C>
+struct Ops {
+    typedef typename C::Fr Fr;
+    typedef typename C::Fq Fq;
+    typedef typename C::Fq2 Fq2;
+
+    template <class F>
+    static hk_status msm_plain(hk_ctx* ctx, const void* bases, size_t n_bases, const void* scalars,
+                               size_t n_scalars, int mont, int checked, void* out) {
+        if (checked && n_bases != n_scalars) return HK_ERR_LEN;     // ark `msm`: Err(min_len)
+        size_t n = n_bases < n_scalars ? n_bases : n_scalars;      // ark `msm_unchecked`: zip
+        if (n == 0) { memset(out, 0, sizeof(Affine<F>)); return HK_OK; }
+        if (!bases || !scalars) return HK_ERR_ARG;
+        if (n >= (1u << 26)) return HK_ERR_ARG;
+        LaneGuard g(ctx);
+        Lane* L = g.lane;
+        if (!L) return HK_ERR_DEVICE;
+        u32 c = msm_pick_c_plain(n, C::FR_BITS);
+        MsmPlan p = msm_make_plan((u32)n, C::FR_BITS, c, 0xffffffffu, ctx->max_lanes0);
+        size_t need = al256(n * sizeof(Fr)) + al256(n * sizeof(Affine<F>)) + msm_sort_bytes(p) +
+                      msm_run_bytes<F>(p) + al256(sizeof(XYZZ<F>)) + al256(sizeof(Affine<F>)) + 4096;
+        HK_TRY(L->reserve(need));
+        const void *sc_d, *b_d;
+        HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sc_d));
+        HK_TRY(to_device(L, bases, n * sizeof(Affine<F>), &b_d));
+        SortBufs sb;
+        HK_TRY(MsmSort<Fr>::alloc(L, p, &sb));
+        typename MsmRun<F>::Bufs rb;
+        HK_TRY(MsmRun<F>::alloc(L, p, &rb));
+        XYZZ<F>* res = L->alloc_n<XYZZ<F>>(1);
+        Affine<F>* aff = L->alloc_n<Affine<F>>(1);
+        if (!res || !aff) return HK_ERR_NOMEM;
+        HK_TRY(MsmSort<Fr>::run(L, p, (const u32*)sc_d, mont, sb));
+        HK_TRY(MsmRun<F>::run(L, p, (const Affine<F>*)b_d, (u32)n, 0, sb, rb, res, nullptr, nullptr));
+        HK_TRY(MsmRun<F>::to_affine(L->stream, res, aff, 1));
+        HK_HIP(hipMemcpyAsync(out, aff, sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+        HK_HIP(hipStreamSynchronize(L->stream));
+        return HK_OK;
+    }
+
+    static hk_status msm(hk_ctx* ctx, int group, const void* bases, size_t n_bases, const void* scalars,
+                         size_t n_scalars, int mont, int checked, void* out) {
+        if (group == 1) return msm_plain<Fq>(ctx, bases, n_bases, scalars, n_scalars, mont, checked, out);
+        return msm_plain<Fq2>(ctx, bases, n_bases, scalars, n_scalars, mont, checked, out);
+    }
+
+    // ---- filled in by later includes (ntt / qap / prove) -------------------------------------------
+    static hk_status ntt(hk_ctx*, void*, unsigned, int, int);
+    static hk_status witness_map(hk_ctx*, const hk_csr*, const hk_csr*, const hk_csr*, size_t, size_t,
+                                 const void*, size_t, void*, size_t, size_t*);
+    static hk_status pk_upload(hk_ctx*, const hk_pk_desc*, hk_pk**);
+    static void pk_free(hk_pk*);
+    static hk_status commit(hk_ctx*, const hk_pk*, size_t, const void*, size_t, const void*, void*);
+    static hk_status prove(hk_ctx*, const hk_pk*, const void*, size_t, const void*, const void*,
+                           const void*, size_t, void*, void*, void*);
+    static void ctx_release(hk_ctx*);
+
+    static const CurveOps* table() {
+        static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
+                                   &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
+                                   &ctx_release};
+        return &t;
+    }
+};
+
+}  // namespace hk

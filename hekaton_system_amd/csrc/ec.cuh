@@ -6,6 +6,12 @@
 #pragma once
 #include "field.cuh"
 
+#if defined(__HIPCC__)
+#define HK_RARE __host__ __device__ __noinline__
+#else
+#define HK_RARE inline
+#endif
+
 namespace hk {
 
 template <class F>
@@ -30,9 +36,10 @@ struct XYZZ {
     }
 };
 
-// 2*(x,y) for an affine, non-infinity point ("mdbl-2008-s-1", a = 0)
+// 2*(x,y) for an affine, non-infinity point ("mdbl-2008-s-1", a = 0); only reached from the
+// P == Q corner of ec_madd, so kept out of line
 template <class F>
-HK_HD XYZZ<F> ec_dbl_affine(const Affine<F>& p) {
+HK_RARE XYZZ<F> ec_dbl_affine(const Affine<F>& p) {
     F u = F::dbl(p.y);
     F v = F::sqr(u);
     F w = F::mul(u, v);
@@ -64,6 +71,9 @@ HK_HD XYZZ<F> ec_dbl(const XYZZ<F>& p) {
     r.zzz = F::mul(w, p.zzz);
     return r;
 }
+
+template <class F>
+HK_RARE XYZZ<F> ec_dbl_rare(const XYZZ<F>& p) { return ec_dbl(p); }
 
 // acc + affine q  ("madd-2008-s"), all exceptional cases handled
 template <class F>
@@ -101,7 +111,7 @@ HK_HD XYZZ<F> ec_add(const XYZZ<F>& a, const XYZZ<F>& b) {
     F p = F::sub(u2, u1);
     F r = F::sub(s2, s1);
     if (p.is_zero()) {
-        if (r.is_zero()) return ec_dbl(a);
+        if (r.is_zero()) return ec_dbl_rare(a);
         return XYZZ<F>::inf();
     }
     F pp = F::sqr(p);
@@ -114,6 +124,22 @@ HK_HD XYZZ<F> ec_add(const XYZZ<F>& a, const XYZZ<F>& b) {
     o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
     return o;
 }
+
+// out-of-line forms for the latency-bound tail kernels (keeps code size and compile time down)
+template <class F>
+HK_RARE XYZZ<F> ec_add_ni(const XYZZ<F>& a, const XYZZ<F>& b) { return ec_add(a, b); }
+template <class F>
+HK_RARE XYZZ<F> ec_dbl_ni(const XYZZ<F>& a) { return ec_dbl(a); }
+template <class F>
+HK_RARE XYZZ<F> ec_madd_ni(const XYZZ<F>& a, const Affine<F>& b) { return ec_madd(a, b); }
+template <class F>
+HK_RARE F f_mul_ni(const F& a, const F& b) { return F::mul(a, b); }
+
+#if defined(__HIPCC__)
+#define HK_NOUNROLL _Pragma("unroll 1")
+#else
+#define HK_NOUNROLL
+#endif
 
 template <class F>
 HK_HD Affine<F> ec_neg(const Affine<F>& p) {
@@ -130,9 +156,9 @@ HK_HD XYZZ<F> ec_neg(const XYZZ<F>& p) {
 template <class F>
 HK_HD XYZZ<F> ec_mul_small(const XYZZ<F>& p, u32 k) {
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (int bit = 31; bit >= 0; bit--) {
-        acc = ec_dbl(acc);
-        if ((k >> bit) & 1) acc = ec_add(acc, p);
+    HK_NOUNROLL for (int bit = 31; bit >= 0; bit--) {
+        acc = ec_dbl_ni(acc);
+        if ((k >> bit) & 1) acc = ec_add_ni(acc, p);
     }
     return acc;
 }
@@ -141,10 +167,10 @@ HK_HD XYZZ<F> ec_mul_small(const XYZZ<F>& p, u32 k) {
 template <class F, int NL>
 HK_HD XYZZ<F> ec_mul_limbs(const XYZZ<F>& p, const u32 (&k)[NL]) {
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (int i = NL - 1; i >= 0; i--) {
-        for (int bit = 31; bit >= 0; bit--) {
-            acc = ec_dbl(acc);
-            if ((k[i] >> bit) & 1) acc = ec_add(acc, p);
+    HK_NOUNROLL for (int i = NL - 1; i >= 0; i--) {
+        HK_NOUNROLL for (int bit = 31; bit >= 0; bit--) {
+            acc = ec_dbl_ni(acc);
+            if ((k[i] >> bit) & 1) acc = ec_add_ni(acc, p);
         }
     }
     return acc;
@@ -162,11 +188,11 @@ HK_HD Fp<P> fp_inv(const Fp<P>& a) {
         borrow = (m < borrow) ? 1u : 0u;
     }
     Fp<P> result = Fp<P>::one();
-    for (int i = P::N - 1; i >= 0; i--) {
+    HK_NOUNROLL for (int i = P::N - 1; i >= 0; i--) {
         u32 e = ex[i];
-        for (int bit = 31; bit >= 0; bit--) {
-            result = Fp<P>::sqr(result);
-            if ((e >> bit) & 1) result = Fp<P>::mul(result, a);
+        HK_NOUNROLL for (int bit = 31; bit >= 0; bit--) {
+            result = f_mul_ni(result, result);
+            if ((e >> bit) & 1) result = f_mul_ni(result, a);
         }
     }
     return result;
@@ -174,11 +200,11 @@ HK_HD Fp<P> fp_inv(const Fp<P>& a) {
 template <class P>
 HK_HD Fp2<P> fp_inv(const Fp2<P>& a) {
     typedef Fp<P> B;
-    B n = B::add(B::sqr(a.c0), B::sqr(a.c1));
+    B n = B::add(f_mul_ni(a.c0, a.c0), f_mul_ni(a.c1, a.c1));
     B ni = fp_inv(n);
     Fp2<P> r;
-    r.c0 = B::mul(a.c0, ni);
-    r.c1 = B::neg(B::mul(a.c1, ni));
+    r.c0 = f_mul_ni(a.c0, ni);
+    r.c1 = B::neg(f_mul_ni(a.c1, ni));
     return r;
 }
 
@@ -187,10 +213,10 @@ HK_HD Affine<F> ec_to_affine(const XYZZ<F>& p) {
     if (p.is_inf()) return Affine<F>::inf();
     // 1/zzz, then 1/zz = zzz^-2 * zz^2  (zz^3 = zzz^2  =>  zz^-1 = zz^2 / zzz^2)
     F zzz_inv = fp_inv(p.zzz);
-    F zz_inv = F::mul(F::sqr(zzz_inv), F::sqr(p.zz));
+    F zz_inv = f_mul_ni(f_mul_ni(zzz_inv, zzz_inv), f_mul_ni(p.zz, p.zz));
     Affine<F> r;
-    r.x = F::mul(p.x, zz_inv);
-    r.y = F::mul(p.y, zzz_inv);
+    r.x = f_mul_ni(p.x, zz_inv);
+    r.y = f_mul_ni(p.y, zzz_inv);
     return r;
 }
 

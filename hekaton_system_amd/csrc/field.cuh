@@ -13,9 +13,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HK_HD __host__ __device__ __forceinline__
+#define HK_CALL __host__ __device__ __noinline__
 #define HK_UNROLL _Pragma("unroll")
 #else
 #define HK_HD inline
+#define HK_CALL inline
 #define HK_UNROLL
 #endif
 
@@ -160,6 +162,9 @@ struct Fp {
         return reduce_once(r);
     }
     HK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
+    // out-of-line product with by-value (register) arguments: lets big callers (Fp2 / G2 code) keep
+    // their state in registers around a compact callee instead of inlining 500 instructions per use
+    HK_CALL static Fp mul_call(Fp a, Fp b) { return mul(a, b); }
 
     // canonical integer -> Montgomery, Montgomery -> canonical
     HK_HD static Fp to_mont(const Fp& a) { return mul(a, r2()); }
@@ -188,18 +193,18 @@ struct Fp2 {
     HK_HD static Fp2 dbl(const Fp2& a) { return add(a, a); }
     HK_HD static Fp2 neg(const Fp2& a) { Fp2 r; r.c0 = B::neg(a.c0); r.c1 = B::neg(a.c1); return r; }
     HK_HD static Fp2 mul(const Fp2& a, const Fp2& b) {       // Karatsuba, 3 base muls
-        B v0 = B::mul(a.c0, b.c0);
-        B v1 = B::mul(a.c1, b.c1);
-        B s = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        B v0 = B::mul_call(a.c0, b.c0);
+        B v1 = B::mul_call(a.c1, b.c1);
+        B s = B::mul_call(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
         Fp2 r;
         r.c0 = B::sub(v0, v1);
         r.c1 = B::sub(B::sub(s, v0), v1);
         return r;
     }
     HK_HD static Fp2 sqr(const Fp2& a) {                     // (a0+a1)(a0-a1), 2 a0 a1
-        B t = B::mul(a.c0, a.c1);
+        B t = B::mul_call(a.c0, a.c1);
         Fp2 r;
-        r.c0 = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
+        r.c0 = B::mul_call(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
         r.c1 = B::dbl(t);
         return r;
     }

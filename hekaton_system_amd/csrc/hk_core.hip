@@ -1,0 +1,234 @@
+// hk_core.hip — context / lane management and the C ABI entry points (dispatch to per-curve code).
+#include "hk_internal.h"
+
+namespace hk {
+
+hk_status Lane::reserve(size_t bytes) {
+    arena_off = 0;
+    if (bytes <= arena_cap) return HK_OK;
+    HK_HIP(hipStreamSynchronize(stream));
+    if (arena) HK_HIP(hipFree(arena));
+    arena = nullptr;
+    arena_cap = 0;
+    size_t want = bytes + bytes / 8 + (1u << 20);
+    hipError_t e = hipMalloc((void**)&arena, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fprintf(stderr, "[hekaton] scratch allocation of %zu bytes failed: %s\n", want, hipGetErrorName(e));
+        return HK_ERR_NOMEM;
+    }
+    arena_cap = want;
+    return HK_OK;
+}
+
+LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    for (;;) {
+        for (Lane* l : ctx->lanes)
+            if (!l->busy) { lane = l; break; }
+        if (lane) break;
+        if (ctx->lanes.size() < ctx->max_lanes) {
+            Lane* l = new Lane();
+            (void)hipSetDevice(ctx->device);
+            if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) { delete l; break; }
+            for (auto& e : l->ev) (void)hipEventCreate(&e);
+            memset(&l->timings, 0, sizeof(l->timings));
+            ctx->lanes.push_back(l);
+            lane = l;
+            break;
+        }
+        ctx->cv.wait(lk);
+    }
+    if (lane) lane->busy = true;
+    lk.unlock();
+    (void)hipSetDevice(ctx->device);
+}
+
+LaneGuard::~LaneGuard() {
+    if (!lane) return;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    lane->busy = false;
+    ctx->last = lane->timings;
+    lk.unlock();
+    ctx->cv.notify_one();
+}
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+hk_status to_device(Lane* L, const void* p, size_t bytes, const void** out) {
+    if (bytes == 0) { *out = p; return HK_OK; }
+    if (is_device_ptr(p)) { *out = p; return HK_OK; }
+    void* d = L->alloc(bytes);
+    if (!d) return HK_ERR_NOMEM;
+    HK_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, L->stream));
+    *out = d;
+    return HK_OK;
+}
+
+}  // namespace hk
+
+using namespace hk;
+
+extern "C" {
+
+const char* hk_status_str(hk_status s) {
+    switch (s) {
+        case HK_OK: return "HK_OK";
+        case HK_ERR_LEN: return "HK_ERR_LEN";
+        case HK_ERR_DOMAIN_TOO_LARGE: return "HK_ERR_DOMAIN_TOO_LARGE";
+        case HK_ERR_DEVICE: return "HK_ERR_DEVICE";
+        case HK_ERR_ARG: return "HK_ERR_ARG";
+        case HK_ERR_NOMEM: return "HK_ERR_NOMEM";
+    }
+    return "HK_ERR_UNKNOWN";
+}
+
+const char* hk_version(void) { return "hekaton-mi355x 0.1 (gfx950)"; }
+
+hk_status hk_ctx_create(hk_curve curve, int device_id, hk_ctx** out) {
+    if (!out) return HK_ERR_ARG;
+    *out = nullptr;
+    if (curve != HK_BN254 && curve != HK_BLS12_381) return HK_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        fprintf(stderr, "[hekaton] no HIP device: this library has no CPU path\n");
+        return HK_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) return HK_ERR_DEVICE;
+    HK_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HK_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "[hekaton] device %d is %s; kernels are built for gfx950 only\n", device_id,
+                prop.gcnArchName);
+        return HK_ERR_DEVICE;
+    }
+    hk_ctx* c = new hk_ctx();
+    c->curve = curve;
+    c->device = device_id;
+    c->ops = curve == HK_BN254 ? curve_ops_bn254() : curve_ops_bls381();
+    memset(&c->last, 0, sizeof(c->last));
+    const char* ml = getenv("HK_MAX_LANES");
+    if (ml && atoi(ml) > 0) c->max_lanes = (size_t)atoi(ml);
+    *out = c;
+    return HK_OK;
+}
+
+void hk_ctx_destroy(hk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->ops && ctx->ops->ctx_release) ctx->ops->ctx_release(ctx);
+    for (Lane* l : ctx->lanes) {
+        if (l->arena) (void)hipFree(l->arena);
+        if (l->pinned) (void)hipHostFree(l->pinned);
+        for (auto& e : l->ev) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(l->stream);
+        delete l;
+    }
+    delete ctx;
+}
+
+hk_status hk_ctx_sync(hk_ctx* ctx) {
+    if (!ctx) return HK_ERR_ARG;
+    HK_HIP(hipSetDevice(ctx->device));
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    for (Lane* l : ctx->lanes) HK_HIP(hipStreamSynchronize(l->stream));
+    return HK_OK;
+}
+
+hk_status hk_ctx_set_profiling(hk_ctx* ctx, int enable) {
+    if (!ctx) return HK_ERR_ARG;
+    ctx->profiling = enable;
+    return HK_OK;
+}
+
+hk_status hk_ctx_last_timings(hk_ctx* ctx, hk_timings* out) {
+    if (!ctx || !out) return HK_ERR_ARG;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    *out = ctx->last;
+    return HK_OK;
+}
+
+hk_status hk_ctx_sizes(const hk_ctx* ctx, size_t* fr, size_t* fq, size_t* g1, size_t* g2) {
+    if (!ctx) return HK_ERR_ARG;
+    if (fr) *fr = ctx->ops->fr_bytes;
+    if (fq) *fq = ctx->ops->fq_bytes;
+    if (g1) *g1 = ctx->ops->g1_bytes;
+    if (g2) *g2 = ctx->ops->g2_bytes;
+    return HK_OK;
+}
+
+hk_status hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return HK_ERR_ARG;
+    HK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { (void)hipGetLastError(); return HK_ERR_NOMEM; }
+    return HK_OK;
+}
+hk_status hk_dev_free(hk_ctx* ctx, void* dptr) {
+    if (!ctx) return HK_ERR_ARG;
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipFree(dptr));
+    return HK_OK;
+}
+hk_status hk_dev_upload(hk_ctx* ctx, void* dst_d, const void* src_h, size_t bytes) {
+    if (!ctx) return HK_ERR_ARG;
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipMemcpy(dst_d, src_h, bytes, hipMemcpyHostToDevice));
+    return HK_OK;
+}
+hk_status hk_dev_download(hk_ctx* ctx, void* dst_h, const void* src_d, size_t bytes) {
+    if (!ctx) return HK_ERR_ARG;
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipMemcpy(dst_h, src_d, bytes, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+
+hk_status hk_msm_g1(hk_ctx* ctx, const void* bases, size_t n_bases, const void* scalars, size_t n_scalars,
+                    int mont, int checked, void* out) {
+    if (!ctx || !out) return HK_ERR_ARG;
+    return ctx->ops->msm(ctx, 1, bases, n_bases, scalars, n_scalars, mont, checked, out);
+}
+hk_status hk_msm_g2(hk_ctx* ctx, const void* bases, size_t n_bases, const void* scalars, size_t n_scalars,
+                    int mont, int checked, void* out) {
+    if (!ctx || !out) return HK_ERR_ARG;
+    return ctx->ops->msm(ctx, 2, bases, n_bases, scalars, n_scalars, mont, checked, out);
+}
+hk_status hk_ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int coset) {
+    if (!ctx || !data) return HK_ERR_ARG;
+    return ctx->ops->ntt(ctx, data, log_m, inverse, coset);
+}
+hk_status hk_witness_map(hk_ctx* ctx, const hk_csr* A, const hk_csr* B, const hk_csr* C, size_t n_inst,
+                         size_t n_constraints, const void* z_mont, size_t n_v, void* h_out,
+                         size_t h_capacity, size_t* m_out) {
+    if (!ctx || !A || !B || !C || !z_mont || !h_out) return HK_ERR_ARG;
+    return ctx->ops->witness_map(ctx, A, B, C, n_inst, n_constraints, z_mont, n_v, h_out, h_capacity, m_out);
+}
+hk_status hk_pk_upload(hk_ctx* ctx, const hk_pk_desc* desc, hk_pk** out) {
+    if (!ctx || !desc || !out) return HK_ERR_ARG;
+    return ctx->ops->pk_upload(ctx, desc, out);
+}
+void hk_pk_free(hk_pk* pk) {
+    if (!pk) return;
+    pk->ops->pk_free(pk);
+}
+hk_status hk_commit(hk_ctx* ctx, const hk_pk* pk, size_t stage, const void* w, size_t n, const void* kappa,
+                    void* out) {
+    if (!ctx || !pk || !kappa || !out) return HK_ERR_ARG;
+    return ctx->ops->commit(ctx, pk, stage, w, n, kappa, out);
+}
+hk_status hk_prove(hk_ctx* ctx, const hk_pk* pk, const void* z, size_t n_v, const void* r, const void* s,
+                   const void* kappas, size_t n_kappas, void* a, void* b, void* c) {
+    if (!ctx || !pk || !z || !r || !s || !a || !b || !c) return HK_ERR_ARG;
+    return ctx->ops->prove(ctx, pk, z, n_v, r, s, kappas, n_kappas, a, b, c);
+}
+
+}  // extern "C"

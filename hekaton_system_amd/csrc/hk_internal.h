@@ -1,0 +1,134 @@
+// hk_internal.h — context, lanes and scratch arenas shared by the translation units of libhekaton.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/hekaton.h"
+#include "msm.cuh"
+
+#define HK_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            fprintf(stderr, "[hekaton] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e),    \
+                    __FILE__, __LINE__, #expr);                                              \
+            return HK_ERR_DEVICE;                                                            \
+        }                                                                                    \
+    } while (0)
+
+#define HK_TRY(expr)                       \
+    do {                                   \
+        hk_status _s = (expr);             \
+        if (_s != HK_OK) return _s;        \
+    } while (0)
+
+namespace hk {
+
+// ---- curve traits -----------------------------------------------------------------------------
+struct CurveBn254 {
+    typedef Fp<Bn254FrP> Fr;
+    typedef Fp<Bn254FqP> Fq;
+    typedef Fp2<Bn254FqP> Fq2;
+    static constexpr u32 FR_BITS = HK_BN254_FR_BITS;
+    static constexpr u32 TWO_ADICITY = HK_BN254_TWO_ADICITY;
+    static constexpr u32 ROOT[8] = HK_BN254_FR_ROOT;
+    static constexpr u32 GEN[8] = HK_BN254_FR_GEN;
+    static constexpr u32 GEN_INV[8] = HK_BN254_FR_GEN_INV;
+};
+struct CurveBls381 {
+    typedef Fp<Bls381FrP> Fr;
+    typedef Fp<Bls381FqP> Fq;
+    typedef Fp2<Bls381FqP> Fq2;
+    static constexpr u32 FR_BITS = HK_BLS12_381_FR_BITS;
+    static constexpr u32 TWO_ADICITY = HK_BLS12_381_TWO_ADICITY;
+    static constexpr u32 ROOT[8] = HK_BLS12_381_FR_ROOT;
+    static constexpr u32 GEN[8] = HK_BLS12_381_FR_GEN;
+    static constexpr u32 GEN_INV[8] = HK_BLS12_381_FR_GEN_INV;
+};
+
+// ---- per-call lane: one stream + one grow-only scratch arena ---------------------------------------
+struct Lane {
+    hipStream_t stream = nullptr;
+    char* arena = nullptr;
+    size_t arena_cap = 0;
+    size_t arena_off = 0;
+    void* pinned = nullptr;       // small host staging buffer
+    size_t pinned_cap = 0;
+    hipEvent_t ev[16];
+    bool busy = false;
+    hk_timings timings;
+
+    hk_status reserve(size_t bytes);                 // ensure capacity (may sync + realloc), reset
+    void* alloc(size_t bytes) {                      // bump allocation, 256-B aligned
+        size_t off = (arena_off + 255) & ~(size_t)255;
+        if (off + bytes > arena_cap) return nullptr;
+        arena_off = off + bytes;
+        return arena + off;
+    }
+    template <class T> T* alloc_n(size_t n) { return (T*)alloc(n * sizeof(T)); }
+};
+
+struct NttTables;   // ntt.hip
+
+}  // namespace hk
+
+namespace hk {
+// per-curve entry points; each curve's translation unit fills one table
+struct CurveOps {
+    size_t fr_bytes, fq_bytes, g1_bytes, g2_bytes;
+    hk_status (*msm)(hk_ctx*, int group, const void* bases, size_t n_bases, const void* scalars,
+                     size_t n_scalars, int mont, int checked, void* out);
+    hk_status (*ntt)(hk_ctx*, void* data, unsigned log_m, int inverse, int coset);
+    hk_status (*witness_map)(hk_ctx*, const hk_csr* A, const hk_csr* B, const hk_csr* C, size_t n_inst,
+                             size_t n_c, const void* z, size_t n_v, void* h_out, size_t h_cap, size_t* m_out);
+    hk_status (*pk_upload)(hk_ctx*, const hk_pk_desc*, hk_pk**);
+    void (*pk_free)(hk_pk*);
+    hk_status (*commit)(hk_ctx*, const hk_pk*, size_t stage, const void* w, size_t n, const void* kappa,
+                        void* out);
+    hk_status (*prove)(hk_ctx*, const hk_pk*, const void* z, size_t n_v, const void* r, const void* s,
+                       const void* kappas, size_t n_kappas, void* a, void* b, void* c);
+    void (*ctx_release)(hk_ctx*);
+};
+const CurveOps* curve_ops_bn254();
+const CurveOps* curve_ops_bls381();
+}  // namespace hk
+
+struct hk_ctx {
+    hk_curve curve;
+    const hk::CurveOps* ops = nullptr;
+    int device;
+    int profiling = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<hk::Lane*> lanes;
+    size_t max_lanes = 8;
+    hk::NttTables* ntt = nullptr;
+    hk_timings last;
+    uint32_t max_lanes0 = 262144;   // level-0 accumulate lanes (one full-occupancy wave set)
+};
+
+struct hk_pk {
+    const hk::CurveOps* ops;
+    hk_ctx* ctx;
+    void* impl;
+};
+
+namespace hk {
+
+struct LaneGuard {
+    hk_ctx* ctx;
+    Lane* lane;
+    LaneGuard(hk_ctx* c);
+    ~LaneGuard();
+};
+
+bool is_device_ptr(const void* p);
+// returns a device pointer for `p` (copies host data into lane scratch when needed)
+hk_status to_device(Lane* L, const void* p, size_t bytes, const void** out);
+
+}  // namespace hk

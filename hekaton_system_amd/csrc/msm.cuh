@@ -1,0 +1,451 @@
+// msm.cuh — variable-base multi-scalar multiplication (Pippenger bucket method) for CDNA4.
+//
+// Replaces ark-ec `VariableBaseMSM::{msm_bigint,msm,msm_unchecked}` as called by the reference at
+// cp-groth16/src/prover.rs:88,97,107,117,129 and committer.rs:89,113.  The result of an MSM is a
+// unique group element, so any bucket schedule is bit-exact with arkworks once normalised to affine
+// (SURVEY.md A.3); this schedule is designed for MI355X, not translated from ark-ec:
+//
+//   1. k_msm_hist / k_msm_scatter — every scalar is split into W signed c-bit digits with the
+//      "add 2^(c-1) to every window" trick (digits independent, no carry chain); digits are
+//      counting-sorted by bucket with a 128 KiB LDS histogram per workgroup (LDS atomics absorb the
+//      heavy-hitter buckets that SHA-style 0/1 witnesses create) and one global atomic per
+//      (workgroup, non-empty bucket).
+//   2. k_msm_accum0 — the sorted entry list is cut into EQUAL slices, one per lane, regardless of
+//      bucket boundaries (perfect load balance, 64-wide waves never idle on a short bucket); each lane
+//      runs mixed XYZZ adds in registers, writes buckets it fully owns, and emits at most two boundary
+//      partials.
+//   3. k_msm_accum_lvl — the boundary partials (sorted by bucket by construction) are reduced by the
+//      same equal-slice segmented scheme, level by level, until one lane remains.
+//   4. k_msm_bucket_reduce / k_msm_window_sum / k_msm_final — weighted bucket sums, LDS tree, Horner.
+//
+// HBM-first trick: proving-key bases are static, HBM is 288 GB, so hk_pk_upload stores every base
+// together with its 2^(c*WP*g) multiples ("shift tables", k_msm_build_tables).  All windows of a
+// group then share one bucket set and the serial Horner tail shrinks from ~254 doublings to
+// c*(WP-1) (zero when WP == 1).
+#pragma once
+#include "ec.cuh"
+
+namespace hk {
+
+constexpr int MSM_MAX_LEVELS = 10;
+constexpr u32 MSM_LVL_L = 32;          // entries per lane on levels >= 1
+constexpr int MSM_SORT_THREADS = 1024;
+constexpr int MSM_LDS_COUNTERS = 32768; // 128 KiB of LDS per sort workgroup
+
+struct MsmPlan {
+    u32 n;            // scalars / entries per group
+    u32 c;            // window bits
+    u32 B;            // buckets per window = 2^(c-1)
+    u32 W;            // total windows
+    u32 WP;           // windows per group (share Horner); groups F = ceil(W/WP)
+    u32 F;
+    u32 NB;           // WP * B
+    u32 n_levels;
+    u32 T[MSM_MAX_LEVELS];     // lanes launched per level
+    u32 Lmin0;
+    u32 chunk;        // scalars per sort workgroup
+    u32 K;            // buckets per lane in bucket_reduce
+    u32 kconst[10];   // sum_w 2^(c*w + c-1) as 32-bit limbs
+};
+
+// level bookkeeping shared by host and device: how many entries / lanes are live on level k
+struct LevelInfo { u32 count, L, active; };
+HK_HD LevelInfo msm_level_info(const MsmPlan& p, u32 E, int k) {
+    LevelInfo li;
+    li.count = E;
+    u32 L = (E + p.T[0] - 1) / p.T[0];
+    if (L < p.Lmin0) L = p.Lmin0;
+    li.L = L;
+    li.active = (E + L - 1) / L;
+    for (int j = 1; j <= k; j++) {
+        li.count = 2 * li.active;
+        li.L = MSM_LVL_L;
+        li.active = (li.count + li.L - 1) / li.L;
+    }
+    return li;
+}
+
+#if defined(__HIPCC__)
+
+// ---- digit extraction -----------------------------------------------------------------------------
+// s' = s + kconst; digit_w = ((s' >> c*w) & (2^c-1)) - 2^(c-1)  in [-2^(c-1), 2^(c-1)-1]
+template <class Fr>
+__device__ __forceinline__ void msm_load_scalar(const u32* scalars, size_t i, int is_mont,
+                                                const MsmPlan& p, u32 (&sp)[10]) {
+    Fr s;
+    const uint4* src = reinterpret_cast<const uint4*>(scalars + i * Fr::N);
+#pragma unroll
+    for (int k = 0; k < Fr::N / 4; k++) {
+        uint4 v = src[k];
+        s.v[4 * k] = v.x; s.v[4 * k + 1] = v.y; s.v[4 * k + 2] = v.z; s.v[4 * k + 3] = v.w;
+    }
+    if (is_mont) s = Fr::from_mont(s);
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < Fr::N; k++) {
+        carry += (u64)s.v[k] + p.kconst[k];
+        sp[k] = (u32)carry;
+        carry >>= 32;
+    }
+    carry += p.kconst[Fr::N];
+    sp[Fr::N] = (u32)carry;
+    sp[Fr::N + 1] = 0;
+}
+
+__device__ __forceinline__ int msm_digit(const u32 (&sp)[10], u32 w, u32 c) {
+    u32 o = c * w;
+    u32 limb = o >> 5, sh = o & 31;
+    u64 two = ((u64)sp[limb + 1] << 32) | sp[limb];
+    u32 e = (u32)(two >> sh) & ((1u << c) - 1u);
+    return (int)e - (int)(1u << (c - 1));
+}
+
+// ---- counting sort, pass 1: histogram ------------------------------------------------------------
+template <class Fr>
+__global__ void __launch_bounds__(MSM_SORT_THREADS)
+k_msm_hist(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __restrict__ count) {
+    __shared__ u32 h[MSM_LDS_COUNTERS];
+    for (u32 b = threadIdx.x; b < p.NB; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * p.chunk;
+    for (u32 k = threadIdx.x; k < p.chunk; k += blockDim.x) {
+        size_t i = base + k;
+        if (i >= p.n) break;
+        u32 sp[10];
+        msm_load_scalar<Fr>(scalars, i, is_mont, p, sp);
+        for (u32 w = 0; w < p.W; w++) {
+            int d = msm_digit(sp, w, p.c);
+            if (d != 0) {
+                u32 mag = d < 0 ? (u32)(-d) : (u32)d;
+                atomicAdd(&h[(w % p.WP) * p.B + mag - 1], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < p.NB; b += blockDim.x) {
+        u32 v = h[b];
+        if (v) atomicAdd(&count[b], v);
+    }
+}
+
+// ---- exclusive scan of bucket counts (single workgroup) ---------------------------------------------
+template <int UNUSED>
+__global__ void __launch_bounds__(1024)
+k_msm_scan(const u32* __restrict__ count, u32* __restrict__ start, u32* __restrict__ cursor, u32 NB) {
+    __shared__ u32 part[1024];
+    u32 per = (NB + 1023) / 1024;
+    u32 lo = threadIdx.x * per, hi = min(lo + per, NB);
+    u32 s = 0;
+    for (u32 b = lo; b < hi; b++) s += count[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (u32 off = 1; off < 1024; off <<= 1) {
+        u32 v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    u32 run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (u32 b = lo; b < hi; b++) {
+        start[b] = run;
+        cursor[b] = run;
+        run += count[b];
+    }
+    if (threadIdx.x == 1023) start[NB] = part[1023];
+}
+
+// ---- counting sort, pass 2: scatter entry ids ----------------------------------------------------------
+// entry = (group * n + i) | sign << 31
+template <class Fr>
+__global__ void __launch_bounds__(MSM_SORT_THREADS)
+k_msm_scatter(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __restrict__ cursor,
+              u32* __restrict__ sorted) {
+    __shared__ u32 h[MSM_LDS_COUNTERS];
+    for (u32 b = threadIdx.x; b < p.NB; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * p.chunk;
+    for (u32 k = threadIdx.x; k < p.chunk; k += blockDim.x) {
+        size_t i = base + k;
+        if (i >= p.n) break;
+        u32 sp[10];
+        msm_load_scalar<Fr>(scalars, i, is_mont, p, sp);
+        for (u32 w = 0; w < p.W; w++) {
+            int d = msm_digit(sp, w, p.c);
+            if (d != 0) {
+                u32 mag = d < 0 ? (u32)(-d) : (u32)d;
+                atomicAdd(&h[(w % p.WP) * p.B + mag - 1], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // reserve this workgroup's range in every non-empty bucket; h[b] becomes the running position
+    for (u32 b = threadIdx.x; b < p.NB; b += blockDim.x) {
+        u32 v = h[b];
+        if (v) h[b] = atomicAdd(&cursor[b], v);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < p.chunk; k += blockDim.x) {
+        size_t i = base + k;
+        if (i >= p.n) break;
+        u32 sp[10];
+        msm_load_scalar<Fr>(scalars, i, is_mont, p, sp);
+        for (u32 w = 0; w < p.W; w++) {
+            int d = msm_digit(sp, w, p.c);
+            if (d != 0) {
+                u32 mag = d < 0 ? (u32)(-d) : (u32)d;
+                u32 pos = atomicAdd(&h[(w % p.WP) * p.B + mag - 1], 1u);
+                sorted[pos] = ((w / p.WP) * p.n + (u32)i) | (d < 0 ? 0x80000000u : 0u);
+            }
+        }
+    }
+}
+
+// ---- point I/O -----------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T ld_vec(const T* p) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte multiples");
+    T r;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 16); k++) d[k] = s[k];
+    return r;
+}
+template <class T>
+__device__ __forceinline__ void st_vec(T* p, const T& v) {
+    uint4* d = reinterpret_cast<uint4*>(p);
+    const uint4* s = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 16); k++) d[k] = s[k];
+}
+
+// largest b in [0, NB) with start[b] <= pos   (pos < start[NB])
+__device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u32 NB, u32 pos) {
+    u32 lo = 0, hi = NB;   // invariant: start[lo] <= pos < start[hi]
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (start[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- level 0: equal slices of the sorted entry list, mixed adds into registers ---------------------
+// The sorted list was built for `n_entries` scalars per group; this base table has `n_bases` bases per
+// group and its base j corresponds to scalar j + idx_off (the L-query is a suffix of the assignment:
+// cp-groth16/src/prover.rs:111-117 vs :78-82).
+template <class F>
+__global__ void __launch_bounds__(64)
+k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
+             const u32* __restrict__ sorted, const u32* __restrict__ start, MsmPlan p,
+             XYZZ<F>* __restrict__ buckets, u32* __restrict__ pkeys, XYZZ<F>* __restrict__ ppts) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 E = start[p.NB];
+    LevelInfo li = msm_level_info(p, E, 0);
+    if (t >= li.active) return;
+    u32 pos = t * li.L;
+    u32 end = min(pos + li.L, E);
+    u32 b = msm_find_bucket(start, p.NB, pos);
+    bool head_partial = start[b] < pos;
+    bool first = true;
+    u32 first_key = b;
+    u32 boundary = start[b + 1];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZ<F> head = XYZZ<F>::inf();
+    for (; pos < end; pos++) {
+        if (pos == boundary) {
+            // bucket b ended exactly here
+            if (first && head_partial) head = acc;
+            else st_vec(&buckets[b], acc);
+            first = false;
+            acc = XYZZ<F>::inf();
+            do { b++; boundary = start[b + 1]; } while (boundary <= pos);
+        }
+        u32 e = sorted[pos];
+        u32 id = e & 0x7fffffffu;
+        u32 g = id / p.n;
+        u32 i = id - g * p.n;
+        if (i >= idx_off && i - idx_off < n_bases) {
+            Affine<F> P = ld_vec(&bases[(size_t)g * n_bases + (i - idx_off)]);
+            if (e >> 31) P.y = F::neg(P.y);
+            acc = ec_madd(acc, P);
+        }
+    }
+    bool tail_partial = end < boundary;     // bucket b continues in the next lane's slice
+    XYZZ<F> tail = XYZZ<F>::inf();
+    if (first && head_partial) head = acc;              // single run that began before this slice
+    else if (tail_partial) tail = acc;
+    else st_vec(&buckets[b], acc);
+    pkeys[2 * t] = first_key;
+    pkeys[2 * t + 1] = b;
+    st_vec(&ppts[2 * t], head);
+    st_vec(&ppts[2 * t + 1], tail);
+}
+
+// ---- levels >= 1: segmented reduction of boundary partials ---------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64)
+k_msm_accum_lvl(int level, const u32* __restrict__ keys_in, const XYZZ<F>* __restrict__ pts_in,
+                const u32* __restrict__ start, MsmPlan p, XYZZ<F>* __restrict__ buckets,
+                u32* __restrict__ keys_out, XYZZ<F>* __restrict__ pts_out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 E = start[p.NB];
+    LevelInfo li = msm_level_info(p, E, level);
+    if (t >= li.active) return;
+    u32 pos = t * li.L;
+    u32 end = min(pos + li.L, li.count);
+    u32 key = keys_in[pos];
+    bool head_partial = pos > 0 && keys_in[pos - 1] == key;
+    bool first = true;
+    u32 first_key = key;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZ<F> head = XYZZ<F>::inf();
+    for (; pos < end; pos++) {
+        u32 kk = keys_in[pos];
+        if (kk != key) {
+            if (first && head_partial) head = acc;
+            else if (!acc.is_inf()) st_vec(&buckets[key], ec_add_ni(ld_vec(&buckets[key]), acc));
+            first = false;
+            acc = XYZZ<F>::inf();
+            key = kk;
+        }
+        XYZZ<F> q = ld_vec(&pts_in[pos]);
+        if (!q.is_inf()) acc = ec_add(acc, q);
+    }
+    bool tail_partial = end < li.count && keys_in[end] == key;
+    XYZZ<F> tail = XYZZ<F>::inf();
+    if (first && head_partial) head = acc;
+    else if (tail_partial) tail = acc;
+    else if (!acc.is_inf()) st_vec(&buckets[key], ec_add_ni(ld_vec(&buckets[key]), acc));
+    if (level + 1 < (int)p.n_levels) {
+        keys_out[2 * t] = first_key;
+        keys_out[2 * t + 1] = key;
+        st_vec(&pts_out[2 * t], head);
+        st_vec(&pts_out[2 * t + 1], tail);
+    }
+}
+
+// ---- bucket reduction: lane j of window w' owns K consecutive buckets ---------------------------------
+// sum_b (b+1) * bucket[b] over its range = local running sum + (j*K) * (plain sum)
+template <class F>
+__global__ void __launch_bounds__(64)
+k_msm_bucket_reduce(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __restrict__ out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 J = p.B / p.K;
+    if (t >= p.WP * J) return;
+    u32 w = t / J, j = t - w * J;
+    const XYZZ<F>* bk = buckets + (size_t)w * p.B + (size_t)j * p.K;
+    XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
+    for (int b = (int)p.K - 1; b >= 0; b--) {
+        XYZZ<F> q = ld_vec(&bk[b]);
+        run = ec_add_ni(run, q);
+        tot = ec_add_ni(tot, run);
+    }
+    u32 wgt = j * p.K;
+    if (wgt && !run.is_inf()) {
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (int bit = 31 - __clz(wgt); bit >= 0; bit--) {
+            acc = ec_dbl_ni(acc);
+            if ((wgt >> bit) & 1) acc = ec_add_ni(acc, run);
+        }
+        tot = ec_add_ni(tot, acc);
+    }
+    st_vec(&out[t], tot);
+}
+
+// one workgroup per window: LDS tree over the J lane results
+template <class F>
+__global__ void __launch_bounds__(64)
+k_msm_window_sum(const XYZZ<F>* __restrict__ in, MsmPlan p, XYZZ<F>* __restrict__ wsum) {
+    __shared__ XYZZ<F> sh[64];
+    u32 J = p.B / p.K;
+    u32 w = blockIdx.x;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (u32 j = threadIdx.x; j < J; j += 64) acc = ec_add_ni(acc, ld_vec(&in[(size_t)w * J + j]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 off = 32; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            XYZZ<F> a = sh[threadIdx.x], b = sh[threadIdx.x + off];
+            sh[threadIdx.x] = ec_add_ni(a, b);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_vec(&wsum[w], sh[0]);
+}
+
+// Horner over the WP window sums of one MSM: res = sum_w 2^(c w) S_w  (XYZZ out)
+template <class F>
+__global__ void k_msm_final(const XYZZ<F>* __restrict__ wsum, MsmPlan p, XYZZ<F>* __restrict__ res) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    XYZZ<F> acc = ld_vec(&wsum[p.WP - 1]);
+    for (int w = (int)p.WP - 2; w >= 0; w--) {
+        for (u32 k = 0; k < p.c; k++) acc = ec_dbl_ni(acc);
+        acc = ec_add_ni(acc, ld_vec(&wsum[w]));
+    }
+    st_vec(res, acc);
+}
+
+template <class F>
+__global__ void k_to_affine(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, u32 n) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    st_vec(&out[t], ec_to_affine(ld_vec(&in[t])));
+}
+
+// ---- shift tables: table[g][i] = 2^(c*WP*g) * base[i], affine, g = 0..F-1 ----------------------------
+// One lane per base walks the groups; every step is c*WP doublings followed by one inversion.
+template <class F>
+__global__ void __launch_bounds__(64)
+k_msm_build_tables(Affine<F>* __restrict__ table, u32 n, u32 F_groups, u32 shift_bits) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> cur = ld_vec(&table[i]);
+    for (u32 g = 1; g < F_groups; g++) {
+        XYZZ<F> x = XYZZ<F>::from_affine(cur);
+        for (u32 k = 0; k < shift_bits; k++) x = ec_dbl_ni(x);
+        cur = ec_to_affine(x);
+        st_vec(&table[(size_t)g * n + i], cur);
+    }
+}
+
+#endif  // __HIPCC__
+
+// ---- host-side planning -----------------------------------------------------------------------------
+inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) {
+    MsmPlan p;
+    p.n = n;
+    p.c = c;
+    p.B = 1u << (c - 1);
+    p.W = (fr_bits + 2 + c - 1) / c;
+    if (WP > p.W) WP = p.W;
+    p.WP = WP;
+    p.F = (p.W + WP - 1) / WP;
+    p.NB = WP * p.B;
+    p.Lmin0 = 8;
+    u64 emax = (u64)n * p.W;
+    u64 t0 = (emax + p.Lmin0 - 1) / p.Lmin0;
+    if (t0 > max_lanes0) t0 = max_lanes0;
+    if (t0 == 0) t0 = 1;
+    p.T[0] = (u32)t0;
+    int k = 0;
+    while (p.T[k] > 1 && k + 1 < MSM_MAX_LEVELS) {
+        u64 cnt = 2ull * p.T[k];
+        p.T[k + 1] = (u32)((cnt + MSM_LVL_L - 1) / MSM_LVL_L);
+        k++;
+    }
+    p.n_levels = k + 1;
+    // sort workgroups: enough of them to fill 256 CUs, chunks of at least 1024 scalars
+    u32 chunk = (n + 511) / 512;
+    if (chunk < 1024) chunk = 1024;
+    p.chunk = chunk;
+    p.K = p.B >= 16 ? 16 : p.B;
+    for (int i = 0; i < 10; i++) p.kconst[i] = 0;
+    for (u32 w = 0; w < p.W; w++) {
+        u32 bit = c * w + c - 1;
+        p.kconst[bit >> 5] |= 1u << (bit & 31);
+    }
+    return p;
+}
+
+}  // namespace hk

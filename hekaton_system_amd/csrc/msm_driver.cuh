@@ -1,0 +1,44 @@
+// msm_driver.cuh — host-side launch sequences for the MSM kernels of msm.cuh.
+// Declarations only; msm_driver_impl.cuh holds the definitions and is included by the translation
+// unit that explicitly instantiates a (scalar field) or (coordinate field) flavour, so the heavy
+// kernels are compiled once per flavour and in parallel.
+#pragma once
+#include "hk_internal.h"
+
+namespace hk {
+
+struct SortBufs {        // device buffers produced by the counting sort
+    u32* count;          // [NB]
+    u32* start;          // [NB + 1]   start[NB] = number of non-zero digits E
+    u32* cursor;         // [NB]
+    u32* sorted;         // [n * W]    entry ids grouped by bucket
+};
+
+template <class Fr>
+struct MsmSort {
+    static hk_status alloc(Lane* L, const MsmPlan& p, SortBufs* out);
+    // scalars_d: n field elements on the device (canonical, or Montgomery when is_mont)
+    static hk_status run(Lane* L, const MsmPlan& p, const u32* scalars_d, int is_mont,
+                         const SortBufs& sb);
+};
+
+template <class F>
+struct MsmRun {
+    struct Bufs {
+        XYZZ<F>* buckets;        // [NB]
+        u32* pkeys[2];           // boundary-partial keys, ping-pong
+        XYZZ<F>* ppts[2];
+        XYZZ<F>* red;            // [WP * B / K]
+        XYZZ<F>* wsum;           // [WP]
+    };
+    static hk_status alloc(Lane* L, const MsmPlan& p, Bufs* out);
+    // table: F shift groups of n_bases affine points each.  result_d receives one XYZZ point.
+    // ev0/ev1 (optional) bracket the bucket-accumulate launches for hk_timings.
+    static hk_status run(Lane* L, const MsmPlan& p, const Affine<F>* table, u32 n_bases, u32 idx_off,
+                         const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
+                         hipEvent_t ev0, hipEvent_t ev1);
+    static hk_status build_tables(hipStream_t s, Affine<F>* table, u32 n, u32 groups, u32 shift_bits);
+    static hk_status to_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, u32 n);
+};
+
+}  // namespace hk

@@ -1,0 +1,90 @@
+// msm_driver_impl.cuh — definitions for msm_driver.cuh (see there).
+#pragma once
+#include "msm_driver.cuh"
+
+namespace hk {
+
+template <class Fr>
+hk_status MsmSort<Fr>::alloc(Lane* L, const MsmPlan& p, SortBufs* out) {
+    out->count = L->alloc_n<u32>(p.NB);
+    out->start = L->alloc_n<u32>(p.NB + 1);
+    out->cursor = L->alloc_n<u32>(p.NB);
+    out->sorted = L->alloc_n<u32>((size_t)p.n * p.W + 1);
+    if (!out->count || !out->start || !out->cursor || !out->sorted) return HK_ERR_NOMEM;
+    return HK_OK;
+}
+
+template <class Fr>
+hk_status MsmSort<Fr>::run(Lane* L, const MsmPlan& p, const u32* scalars_d, int is_mont,
+                           const SortBufs& sb) {
+    if (p.NB > (u32)MSM_LDS_COUNTERS) return HK_ERR_ARG;
+    HK_HIP(hipMemsetAsync(sb.count, 0, sizeof(u32) * p.NB, L->stream));
+    u32 blocks = (p.n + p.chunk - 1) / p.chunk;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL((k_msm_hist<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, L->stream,
+                       scalars_d, is_mont, p, sb.count);
+    hipLaunchKernelGGL((k_msm_scan<0>), dim3(1), dim3(1024), 0, L->stream, sb.count, sb.start, sb.cursor, p.NB);
+    hipLaunchKernelGGL((k_msm_scatter<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, L->stream,
+                       scalars_d, is_mont, p, sb.cursor, sb.sorted);
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
+template <class F>
+hk_status MsmRun<F>::alloc(Lane* L, const MsmPlan& p, Bufs* out) {
+    out->buckets = L->alloc_n<XYZZ<F>>(p.NB);
+    size_t n0 = 2ull * p.T[0];
+    size_t n1 = p.n_levels > 1 ? 2ull * p.T[1] : 2;
+    out->pkeys[0] = L->alloc_n<u32>(n0);
+    out->ppts[0] = L->alloc_n<XYZZ<F>>(n0);
+    out->pkeys[1] = L->alloc_n<u32>(n1);
+    out->ppts[1] = L->alloc_n<XYZZ<F>>(n1);
+    out->red = L->alloc_n<XYZZ<F>>((size_t)p.WP * (p.B / p.K));
+    out->wsum = L->alloc_n<XYZZ<F>>(p.WP);
+    if (!out->buckets || !out->pkeys[0] || !out->ppts[0] || !out->pkeys[1] || !out->ppts[1] ||
+        !out->red || !out->wsum)
+        return HK_ERR_NOMEM;
+    return HK_OK;
+}
+
+template <class F>
+hk_status MsmRun<F>::run(Lane* L, const MsmPlan& p, const Affine<F>* table, u32 n_bases, u32 idx_off,
+                         const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
+                         hipEvent_t ev0, hipEvent_t ev1) {
+    hipStream_t s = L->stream;
+    HK_HIP(hipMemsetAsync(b.buckets, 0, sizeof(XYZZ<F>) * p.NB, s));
+    if (ev0) HK_HIP(hipEventRecord(ev0, s));
+    hipLaunchKernelGGL((k_msm_accum0<F>), dim3((p.T[0] + 63) / 64), dim3(64), 0, s,
+                       table, n_bases, idx_off, sb.sorted, sb.start, p, b.buckets, b.pkeys[0], b.ppts[0]);
+    if (ev1) HK_HIP(hipEventRecord(ev1, s));
+    for (u32 k = 1; k < p.n_levels; k++) {
+        int in = (k - 1) & 1, out = k & 1;
+        hipLaunchKernelGGL((k_msm_accum_lvl<F>), dim3((p.T[k] + 63) / 64), dim3(64), 0, s,
+                           (int)k, b.pkeys[in], b.ppts[in], sb.start, p, b.buckets, b.pkeys[out], b.ppts[out]);
+    }
+    u32 J = p.B / p.K;
+    hipLaunchKernelGGL((k_msm_bucket_reduce<F>), dim3((p.WP * J + 63) / 64), dim3(64), 0, s,
+                       b.buckets, p, b.red);
+    hipLaunchKernelGGL((k_msm_window_sum<F>), dim3(p.WP), dim3(64), 0, s, b.red, p, b.wsum);
+    hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, s, b.wsum, p, result_d);
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
+template <class F>
+hk_status MsmRun<F>::build_tables(hipStream_t s, Affine<F>* table, u32 n, u32 groups, u32 shift_bits) {
+    if (groups <= 1 || n == 0) return HK_OK;
+    hipLaunchKernelGGL((k_msm_build_tables<F>), dim3((n + 63) / 64), dim3(64), 0, s, table, n, groups,
+                       shift_bits);
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
+template <class F>
+hk_status MsmRun<F>::to_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, u32 n) {
+    hipLaunchKernelGGL((k_to_affine<F>), dim3((n + 63) / 64), dim3(64), 0, s, in, out, n);
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
+}  // namespace hk

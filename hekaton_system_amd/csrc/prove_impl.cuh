@@ -1,0 +1,700 @@
+// prove_impl.cuh — per-curve host orchestration of the CP-Groth16 hot path on one GPU:
+// NTT / witness map, proving-key residency (shift tables), hk_commit and hk_prove.
+//
+// Reference path restated (all arithmetic on the device; this file only sequences launches):
+//   CPGroth16::prove_last_stage            cp-groth16/src/prover.rs:78-155
+//   CommitmentBuilder::{commit,prove}      cp-groth16/src/committer.rs:87-91, 112-114
+//   LibsnarkReduction::witness_map         ark-groth16 0.4, called at prover.rs:123
+//
+// Fusion specific to this design: the O(1) fixed-base scalar multiplications of the reference
+// (r*delta, s*delta, r*s*delta, kappa_i*delta_i — prover.rs:86,96,106,135; committer.rs:113) ride the
+// big MSMs as extra (base, scalar) pairs appended to the assignment ("ext" slots), so only the two
+// genuinely variable-base products s*A and r*B1 remain for the finish kernel.
+#pragma once
+#include <string>
+#include "curve_ops_impl.cuh"
+#include "ntt.cuh"
+
+namespace hk {
+
+// ---- small host helpers on Montgomery values (setup constants only) -------------------------------
+template <class Fr>
+static Fr host_halve(const Fr& a) {          // a/2 in the field (works on Montgomery residues too)
+    u32 t[Fr::N + 1];
+    u64 c = 0;
+    bool odd = a.v[0] & 1;
+    for (int i = 0; i < Fr::N; i++) {
+        c += (u64)a.v[i] + (odd ? Fr::Params::MOD[i] : 0u);
+        t[i] = (u32)c;
+        c >>= 32;
+    }
+    t[Fr::N] = (u32)c;
+    Fr r;
+    for (int i = 0; i < Fr::N; i++) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    return r;
+}
+template <class Fr>
+static Fr host_from_limbs(const u32* l) {
+    Fr r;
+    for (int i = 0; i < Fr::N; i++) r.v[i] = l[i];
+    return r;
+}
+
+// ---- twiddle / coset tables (one set per context) ---------------------------------------------------
+struct NttTables {
+    std::mutex mu;
+    u32 log_table = 0;
+    void* tw_fwd = nullptr;      // w_M^i,  i < M/2
+    void* tw_inv = nullptr;      // w_M^-i
+    void* pw_g = nullptr;        // 3 x 1024 powers of F::GENERATOR
+    void* pw_ginv = nullptr;
+    std::vector<void*> retired;  // superseded tables stay alive until the context dies
+};
+
+template <class C>
+struct NttHost {
+    typedef typename C::Fr Fr;
+
+    static hk_status ensure(hk_ctx* ctx, u32 log_m, NttTables** out) {
+        if (log_m > C::TWO_ADICITY) return HK_ERR_DOMAIN_TOO_LARGE;
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        if (!ctx->ntt) ctx->ntt = new NttTables();
+        NttTables* T = ctx->ntt;
+        lk.unlock();
+        std::unique_lock<std::mutex> tl(T->mu);
+        *out = T;
+        if (T->log_table >= log_m && T->tw_fwd) return HK_OK;
+        u32 L = log_m < 16 ? 16 : log_m;
+        if (L > C::TWO_ADICITY) L = C::TWO_ADICITY;
+        HK_HIP(hipSetDevice(ctx->device));
+        // host: w_M = ROOT^(2^(s-L)); sq[k] = w_M^(2^k); w_M^-1 = prod_k sq[k]
+        std::vector<Fr> sq(32), sqi(32);
+        Fr w = host_from_limbs<Fr>(C::ROOT);
+        for (u32 k = 0; k < C::TWO_ADICITY - L; k++) w = Fr::sqr(w);
+        Fr winv = Fr::one();
+        for (u32 k = 0; k < L; k++) {
+            sq[k] = w;
+            winv = Fr::mul(winv, w);
+            w = Fr::sqr(w);
+        }
+        Fr t = winv;
+        for (u32 k = 0; k < L; k++) { sqi[k] = t; t = Fr::sqr(t); }
+        std::vector<Fr> gs(30), gis(30);
+        Fr g = host_from_limbs<Fr>(C::GEN), gi = host_from_limbs<Fr>(C::GEN_INV);
+        for (u32 k = 0; k < 30; k++) { gs[k] = g; gis[k] = gi; g = Fr::sqr(g); gi = Fr::sqr(gi); }
+        Fr *d_sq = nullptr, *tf = nullptr, *ti = nullptr, *pg = nullptr, *pgi = nullptr;
+        size_t half = (size_t)1 << (L - 1);
+        HK_HIP(hipMalloc((void**)&d_sq, sizeof(Fr) * 124));
+        HK_HIP(hipMalloc((void**)&tf, sizeof(Fr) * half));
+        HK_HIP(hipMalloc((void**)&ti, sizeof(Fr) * half));
+        HK_HIP(hipMalloc((void**)&pg, sizeof(Fr) * 3072));
+        HK_HIP(hipMalloc((void**)&pgi, sizeof(Fr) * 3072));
+        HK_HIP(hipMemcpy(d_sq, sq.data(), sizeof(Fr) * 32, hipMemcpyHostToDevice));
+        HK_HIP(hipMemcpy(d_sq + 32, sqi.data(), sizeof(Fr) * 32, hipMemcpyHostToDevice));
+        HK_HIP(hipMemcpy(d_sq + 64, gs.data(), sizeof(Fr) * 30, hipMemcpyHostToDevice));
+        HK_HIP(hipMemcpy(d_sq + 94, gis.data(), sizeof(Fr) * 30, hipMemcpyHostToDevice));
+        u32 blocks = (u32)((half + 255) / 256);
+        hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, 0, tf, d_sq, (u32)half, L - 1);
+        hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, 0, ti, d_sq + 32, (u32)half, L - 1);
+        for (int lvl = 0; lvl < 3; lvl++) {
+            hipLaunchKernelGGL((k_pow_table<Fr>), dim3(4), dim3(256), 0, 0, pg + 1024 * lvl,
+                               d_sq + 64 + 10 * lvl, 1024u, 10u);
+            hipLaunchKernelGGL((k_pow_table<Fr>), dim3(4), dim3(256), 0, 0, pgi + 1024 * lvl,
+                               d_sq + 94 + 10 * lvl, 1024u, 10u);
+        }
+        HK_HIP(hipGetLastError());
+        HK_HIP(hipDeviceSynchronize());
+        HK_HIP(hipFree(d_sq));
+        for (void* p : {T->tw_fwd, T->tw_inv, T->pw_g, T->pw_ginv})
+            if (p) T->retired.push_back(p);
+        T->tw_fwd = tf; T->tw_inv = ti; T->pw_g = pg; T->pw_ginv = pgi;
+        T->log_table = L;
+        return HK_OK;
+    }
+
+    static Fr size_inv(u32 log_m) {               // (2^log_m)^-1, Montgomery
+        Fr x = Fr::one();
+        for (u32 k = 0; k < log_m; k++) x = host_halve(x);
+        return x;
+    }
+    static Fr vanishing_inv_on_coset(u32 log_m) {  // (g^m - 1)^-1  (SURVEY.md A.1 `zinv`)
+        Fr g = host_from_limbs<Fr>(C::GEN);
+        for (u32 k = 0; k < log_m; k++) g = Fr::sqr(g);
+        return fp_inv(Fr::sub(g, Fr::one()));
+    }
+
+    // all butterfly stages of a size-2^logn transform, `batch` vectors `stride` elements apart
+    static hk_status passes(hipStream_t s, Fr* data, size_t stride, u32 batch, u32 logn, const Fr* tw,
+                            u32 log_table, int dit) {
+        if (logn == 0) return HK_OK;
+        // bottom pass takes up to 11 stages (tile = 2^11 contiguous elements), the rest split evenly
+        u32 bottom = logn < 11 ? logn : 11;
+        u32 rest = logn - bottom;
+        u32 npass = (rest + NTT_TILE_LOG_ROWS - 1) / NTT_TILE_LOG_ROWS;
+        struct P { u32 lo, nst; } ps[8];
+        int np = 0;
+        ps[np++] = {0, bottom};
+        u32 lo = bottom;
+        for (u32 i = 0; i < npass; i++) {
+            u32 nst = (rest - (lo - bottom) + (npass - i) - 1) / (npass - i);
+            ps[np++] = {lo, nst};
+            lo += nst;
+        }
+        for (int k = 0; k < np; k++) {
+            const P& p = dit ? ps[k] : ps[np - 1 - k];
+            u32 cols_bits = p.lo < (u32)NTT_TILE_LOG_COLS ? p.lo : (u32)NTT_TILE_LOG_COLS;
+            u32 tile_log = p.nst + cols_bits;
+            u32 tiles = 1u << (logn - tile_log);
+            size_t lds = sizeof(Fr) << tile_log;
+            hipLaunchKernelGGL((k_ntt_pass<Fr>), dim3(tiles, batch), dim3(NTT_THREADS), lds, s, data, stride,
+                               tw, logn, log_table, p.lo, p.nst, dit);
+        }
+        HK_HIP(hipGetLastError());
+        return HK_OK;
+    }
+
+    static hk_status scale(hipStream_t s, Fr* data, size_t stride, u32 batch, u32 logn, const Fr* pw,
+                           const Fr& sc, int bitrev_index, int use_pow) {
+        size_t n = (size_t)1 << logn;
+        hipLaunchKernelGGL((k_scale_pow<Fr>), dim3((u32)((n + 255) / 256), batch), dim3(256), 0, s, data,
+                           stride, pw, sc, logn, bitrev_index, use_pow);
+        HK_HIP(hipGetLastError());
+        return HK_OK;
+    }
+    static hk_status bitrev(hipStream_t s, Fr* data, u32 logn) {
+        size_t n = (size_t)1 << logn;
+        hipLaunchKernelGGL((k_bitrev<Fr>), dim3((u32)((n + 255) / 256)), dim3(256), 0, s, data, logn);
+        HK_HIP(hipGetLastError());
+        return HK_OK;
+    }
+};
+
+template <class C>
+hk_status Ops<C>::ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int coset) {
+    typedef NttHost<C> N;
+    NttTables* T;
+    HK_TRY(N::ensure(ctx, log_m, &T));
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    size_t n = (size_t)1 << log_m;
+    HK_TRY(L->reserve(n * sizeof(Fr) + 4096));
+    bool dev = is_device_ptr(data);
+    Fr* d = (Fr*)data;
+    if (!dev) {
+        d = L->alloc_n<Fr>(n);
+        if (!d) return HK_ERR_NOMEM;
+        HK_HIP(hipMemcpyAsync(d, data, n * sizeof(Fr), hipMemcpyHostToDevice, L->stream));
+    }
+    hipStream_t s = L->stream;
+    if (!inverse) {
+        // coset FFT: coeff j *= g^j, then FFT (A.2).  DIF then un-permute.
+        if (coset) HK_TRY(N::scale(s, d, n, 1, log_m, (const Fr*)T->pw_g, Fr::one(), 0, 1));
+        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_fwd, T->log_table, 0));
+        HK_TRY(N::bitrev(s, d, log_m));
+    } else {
+        // iFFT: DIF with w^-1, scale by 1/m (and g^-j for the coset form), un-permute
+        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0));
+        HK_TRY(N::scale(s, d, n, 1, log_m, (const Fr*)T->pw_ginv, N::size_inv(log_m), 1, coset));
+        HK_TRY(N::bitrev(s, d, log_m));
+    }
+    if (!dev) HK_HIP(hipMemcpyAsync(data, d, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HK_HIP(hipStreamSynchronize(s));
+    return HK_OK;
+}
+
+// ---- witness map on device buffers --------------------------------------------------------------------
+struct CsrDev { const u64* row_ptr; const u32* col; const void* val; size_t n_rows, nnz; };
+
+template <class C>
+struct QapHost {
+    typedef typename C::Fr Fr;
+    typedef NttHost<C> N;
+
+    static u32 domain_log(size_t n_c, size_t n_inst) {
+        size_t need = n_c + n_inst;
+        u32 lg = 0;
+        while (((size_t)1 << lg) < need) lg++;
+        return lg;
+    }
+    // abc: 3*m Fr scratch (a | b | c).  On return a[0..m) = h in BIT-REVERSED order.
+    static hk_status run(hipStream_t s, NttTables* T, const CsrDev& A, const CsrDev& B, const CsrDev& Cm,
+                         size_t n_inst, size_t n_c, const Fr* z, Fr* abc, u32 log_m) {
+        size_t m = (size_t)1 << log_m;
+        HK_HIP(hipMemsetAsync(abc, 0, 3 * m * sizeof(Fr), s));
+        const CsrDev* Ms[3] = {&A, &B, &Cm};
+        for (int k = 0; k < 3; k++) {
+            if (Ms[k]->n_rows == 0) continue;
+            hipLaunchKernelGGL((k_spmv<Fr>), dim3((u32)((Ms[k]->n_rows + 255) / 256)), dim3(256), 0, s,
+                               Ms[k]->row_ptr, Ms[k]->col, (const Fr*)Ms[k]->val, z, abc + k * m,
+                               (u32)Ms[k]->n_rows);
+        }
+        hipLaunchKernelGGL((k_copy_inputs<Fr>), dim3((u32)((n_inst + 255) / 256)), dim3(256), 0, s, abc, z,
+                           (u32)n_c, (u32)n_inst);
+        Fr minv = N::size_inv(log_m);
+        HK_TRY(N::passes(s, abc, m, 3, log_m, (const Fr*)T->tw_inv, T->log_table, 0));       // ifft (DIF)
+        HK_TRY(N::scale(s, abc, m, 3, log_m, (const Fr*)T->pw_g, minv, 1, 1));               // /m, * g^j
+        HK_TRY(N::passes(s, abc, m, 3, log_m, (const Fr*)T->tw_fwd, T->log_table, 1));       // coset fft (DIT)
+        Fr zinv = N::vanishing_inv_on_coset(log_m);
+        hipLaunchKernelGGL((k_qap_combine<Fr>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s, abc, abc + m,
+                           abc + 2 * m, zinv, m);
+        HK_TRY(N::passes(s, abc, m, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0));       // coset ifft
+        HK_TRY(N::scale(s, abc, m, 1, log_m, (const Fr*)T->pw_ginv, minv, 1, 1));
+        HK_HIP(hipGetLastError());
+        return HK_OK;
+    }
+};
+
+template <class C>
+hk_status Ops<C>::witness_map(hk_ctx* ctx, const hk_csr* A, const hk_csr* B, const hk_csr* Cm, size_t n_inst,
+                              size_t n_c, const void* z, size_t n_v, void* h_out, size_t h_cap,
+                              size_t* m_out) {
+    typedef QapHost<C> Q;
+    if (A->n_rows != n_c || B->n_rows != n_c || Cm->n_rows != n_c || n_inst > n_v) return HK_ERR_ARG;
+    u32 log_m = Q::domain_log(n_c, n_inst);
+    if (log_m > C::TWO_ADICITY) return HK_ERR_DOMAIN_TOO_LARGE;
+    size_t m = (size_t)1 << log_m;
+    if (m_out) *m_out = m;
+    if (h_cap < m) return HK_ERR_LEN;
+    NttTables* T;
+    HK_TRY(NttHost<C>::ensure(ctx, log_m, &T));
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    size_t need = 3 * m * sizeof(Fr) + n_v * sizeof(Fr) + 8192;
+    const hk_csr* Ms[3] = {A, B, Cm};
+    for (auto M : Ms) need += al256(8 * (M->n_rows + 1)) + al256(4 * M->nnz) + al256(sizeof(Fr) * M->nnz);
+    HK_TRY(L->reserve(need));
+    CsrDev D[3];
+    for (int k = 0; k < 3; k++) {
+        const void *rp, *cl, *vl;
+        HK_TRY(to_device(L, Ms[k]->row_ptr, 8 * (Ms[k]->n_rows + 1), &rp));
+        HK_TRY(to_device(L, Ms[k]->col, 4 * Ms[k]->nnz, &cl));
+        HK_TRY(to_device(L, Ms[k]->val_mont, sizeof(Fr) * Ms[k]->nnz, &vl));
+        D[k] = {(const u64*)rp, (const u32*)cl, vl, Ms[k]->n_rows, Ms[k]->nnz};
+    }
+    const void* zd;
+    HK_TRY(to_device(L, z, n_v * sizeof(Fr), &zd));
+    Fr* abc = L->alloc_n<Fr>(3 * m);
+    if (!abc) return HK_ERR_NOMEM;
+    HK_TRY(Q::run(L->stream, T, D[0], D[1], D[2], n_inst, n_c, (const Fr*)zd, abc, log_m));
+    HK_TRY(NttHost<C>::bitrev(L->stream, abc, log_m));         // API returns natural order
+    HK_HIP(hipMemcpyAsync(h_out, abc, m * sizeof(Fr),
+                          is_device_ptr(h_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, L->stream));
+    HK_HIP(hipStreamSynchronize(L->stream));
+    return HK_OK;
+}
+
+// ---- device-resident proving key ------------------------------------------------------------------------
+template <class C>
+struct PkImpl {
+    typedef typename C::Fr Fr;
+    typedef typename C::Fq Fq;
+    typedef typename C::Fq2 Fq2;
+    u32 n_v = 0, n_inst = 0, n_c = 0, n_stages = 0, n_ext = 0, n_extra = 0;
+    MsmPlan plan_z;                        // shared by the A / B1 / B2 / L queries (same scalar vector)
+    Affine<Fq>* a_tab = nullptr;           // [F][n_ext]   a_g[1..] | delta_g | inf ...
+    Affine<Fq>* b1_tab = nullptr;          // [F][n_ext]   b_g[1..] | inf | delta_g | inf ...
+    Affine<Fq2>* b2_tab = nullptr;         // [F][n_ext]   b_h[1..] | inf | delta_h | inf ...
+    Affine<Fq>* l_tab = nullptr;           // [F][l_n]     ck_last | inf | inf | -delta_g | -delta_i ...
+    u32 l_n = 0, l_off = 0;
+    bool has_qap = false;
+    u32 log_m = 0;
+    MsmPlan plan_h;
+    Affine<Fq>* h_tab = nullptr;           // [F][m]  h_g in bit-reversed order (slot m-1 = inf)
+    std::vector<MsmPlan> plan_ck;
+    std::vector<Affine<Fq>*> ck_tab;       // [F][ck_len + 1]  ck[stage] | last_delta_g
+    std::vector<u32> ck_n;
+    Affine<Fq>* consts_g1 = nullptr;       // a_g[0], alpha_g, b_g[0], beta_g
+    Affine<Fq2>* consts_g2 = nullptr;      // b_h[0], beta_h
+    CsrDev csr[3];
+    std::vector<void*> owned;              // every hipMalloc of this key
+    size_t bytes = 0;
+};
+
+template <class F>
+static hk_status pk_alloc_table(std::vector<void*>& owned, size_t& total, size_t groups, size_t n,
+                                Affine<F>** out) {
+    size_t b = groups * n * sizeof(Affine<F>);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, b ? b : 16);
+    if (e != hipSuccess) { (void)hipGetLastError(); return HK_ERR_NOMEM; }
+    owned.push_back(p);
+    total += b;
+    *out = (Affine<F>*)p;
+    return HK_OK;
+}
+
+static inline hipMemcpyKind h2d_kind(const void* src) {
+    return is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+}
+
+// scatter h_g into bit-reversed order on the device: tab[bitrev(j)] = h_g[j], j < h_len; others inf
+template <class F>
+__global__ void k_pk_bitrev_copy(Affine<F>* __restrict__ tab, const Affine<F>* __restrict__ src, u32 h_len,
+                                 u32 log_m) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >> log_m) return;
+    u32 r = log_m ? (__brev(j) >> (32 - log_m)) : 0u;
+    Affine<F> p = j < h_len ? ld_vec(&src[j]) : Affine<F>::inf();
+    st_vec(&tab[r], p);
+}
+
+template <class C>
+hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
+    typedef PkImpl<C> PK;
+    *out = nullptr;
+    if (!d->a_g || !d->b_g || !d->b_h || !d->h_g || !d->deltas_g || !d->last_delta_h || !d->alpha_g ||
+        !d->beta_g || !d->beta_h || d->n_stages == 0 || !d->ck_stage || !d->ck_len)
+        return HK_ERR_ARG;
+    size_t n_v = d->a_len;
+    if (n_v < 1 || d->b_g_len != n_v || d->b_h_len != n_v) return HK_ERR_LEN;
+    size_t n_wit = 0;
+    for (size_t s = 0; s < d->n_stages; s++) n_wit += d->ck_len[s];
+    if (d->n_inst < 1 || d->n_inst + n_wit != n_v) return HK_ERR_LEN;   // instance || stage witnesses
+    HK_HIP(hipSetDevice(ctx->device));
+    PK* pk = new PK();
+    hk_pk* h = new hk_pk{ctx->ops, ctx, pk};
+    auto fail = [&](hk_status st) { Ops<C>::pk_free(h); return st; };
+    pk->n_v = (u32)n_v; pk->n_inst = (u32)d->n_inst; pk->n_c = (u32)d->n_constraints;
+    pk->n_stages = (u32)d->n_stages;
+    u32 k = pk->n_stages - 1;
+    pk->n_extra = 3 + k;                               // r, s, r*s, kappa_0..kappa_{k-1}
+    pk->n_ext = (u32)(n_v - 1) + pk->n_extra;
+    const char* wp_env = getenv("HK_MSM_WP");
+    u32 WP = wp_env && atoi(wp_env) > 0 ? (u32)atoi(wp_env) : 1u;
+    auto make_plan = [&](size_t n) {
+        u32 c = msm_pick_c_tables(n, C::FR_BITS);
+        if (WP > 1) { while (c > 5 && ((u64)WP << (c - 1)) > (u64)MSM_LDS_COUNTERS) c--; }
+        return msm_make_plan((u32)n, C::FR_BITS, c, WP, ctx->max_lanes0);
+    };
+    pk->plan_z = make_plan(pk->n_ext);
+    const MsmPlan& pz = pk->plan_z;
+    hipStream_t s0 = 0;
+    size_t g1 = sizeof(Affine<Fq>), g2 = sizeof(Affine<Fq2>);
+    size_t nq = n_v - 1;                                // query[1..]
+    Affine<Fq> inf1 = Affine<Fq>::inf();
+    // --- A / B1 / B2 tables
+    hk_status st;
+    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->a_tab)) != HK_OK) return fail(st);
+    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->b1_tab)) != HK_OK) return fail(st);
+    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->b2_tab)) != HK_OK) return fail(st);
+    HK_HIP(hipMemset(pk->a_tab, 0, g1 * pk->n_ext));
+    HK_HIP(hipMemset(pk->b1_tab, 0, g1 * pk->n_ext));
+    HK_HIP(hipMemset(pk->b2_tab, 0, g2 * pk->n_ext));
+    const char* a_g = (const char*)d->a_g; const char* b_g = (const char*)d->b_g; const char* b_h = (const char*)d->b_h;
+    const char* deltas = (const char*)d->deltas_g;
+    const char* delta_last_g = deltas + g1 * k;
+    if (nq) {
+        HK_HIP(hipMemcpy(pk->a_tab, a_g + g1, g1 * nq, h2d_kind(a_g)));
+        HK_HIP(hipMemcpy(pk->b1_tab, b_g + g1, g1 * nq, h2d_kind(b_g)));
+        HK_HIP(hipMemcpy(pk->b2_tab, b_h + g2, g2 * nq, h2d_kind(b_h)));
+    }
+    HK_HIP(hipMemcpy(pk->a_tab + nq + 0, delta_last_g, g1, h2d_kind(deltas)));          // r * delta_g
+    HK_HIP(hipMemcpy(pk->b1_tab + nq + 1, delta_last_g, g1, h2d_kind(deltas)));         // s * delta_g
+    HK_HIP(hipMemcpy(pk->b2_tab + nq + 1, d->last_delta_h, g2, h2d_kind(d->last_delta_h)));   // s * delta_h
+    u32 shift = pz.c * pz.WP;
+    HK_TRY(MsmRun<Fq>::build_tables(s0, pk->a_tab, pk->n_ext, pz.F, shift));
+    HK_TRY(MsmRun<Fq>::build_tables(s0, pk->b1_tab, pk->n_ext, pz.F, shift));
+    HK_TRY(MsmRun<Fq2>::build_tables(s0, pk->b2_tab, pk->n_ext, pz.F, shift));
+    // --- L table: last-stage committer key, then the negated deltas that fold -rs*delta and -kappa_i*delta_i
+    size_t n1 = d->ck_len[k];
+    pk->l_n = (u32)n1 + pk->n_extra;
+    pk->l_off = (u32)(n_v - 1 - n1);                    // ext index of the first last-stage witness
+    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->l_n, &pk->l_tab)) != HK_OK) return fail(st);
+    HK_HIP(hipMemset(pk->l_tab, 0, g1 * pk->l_n));
+    if (n1) HK_HIP(hipMemcpy(pk->l_tab, d->ck_stage[k], g1 * n1, h2d_kind(d->ck_stage[k])));
+    {
+        std::vector<Affine<Fq>> dh(k + 1);
+        HK_HIP(hipMemcpy(dh.data(), deltas, g1 * (k + 1), is_device_ptr(deltas) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        std::vector<Affine<Fq>> neg(1 + k);
+        neg[0] = dh[k].is_inf() ? dh[k] : ec_neg(dh[k]);                       // -delta_g  (scalar r*s)
+        for (u32 i = 0; i < k; i++) neg[1 + i] = dh[i].is_inf() ? dh[i] : ec_neg(dh[i]);   // -delta_i (kappa_i)
+        HK_HIP(hipMemcpy(pk->l_tab + n1 + 2, neg.data(), g1 * (1 + k), hipMemcpyHostToDevice));
+    }
+    HK_TRY(MsmRun<Fq>::build_tables(s0, pk->l_tab, pk->l_n, pz.F, shift));
+    // --- per-stage commitment tables: ck[stage] | last_delta_g (scalar kappa)
+    for (u32 sidx = 0; sidx < pk->n_stages; sidx++) {
+        size_t n = d->ck_len[sidx] + 1;
+        MsmPlan p = make_plan(n);
+        Affine<Fq>* tab;
+        if ((st = pk_alloc_table(pk->owned, pk->bytes, p.F, n, &tab)) != HK_OK) return fail(st);
+        if (n > 1) HK_HIP(hipMemcpy(tab, d->ck_stage[sidx], g1 * (n - 1), h2d_kind(d->ck_stage[sidx])));
+        HK_HIP(hipMemcpy(tab + n - 1, delta_last_g, g1, h2d_kind(deltas)));
+        HK_TRY(MsmRun<Fq>::build_tables(s0, tab, (u32)n, p.F, p.c * p.WP));
+        pk->plan_ck.push_back(p);
+        pk->ck_tab.push_back(tab);
+        pk->ck_n.push_back((u32)n);
+    }
+    // --- constants for the finish kernel
+    {
+        void* p1; void* p2;
+        HK_HIP(hipMalloc(&p1, g1 * 4)); pk->owned.push_back(p1);
+        HK_HIP(hipMalloc(&p2, g2 * 2)); pk->owned.push_back(p2);
+        pk->consts_g1 = (Affine<Fq>*)p1; pk->consts_g2 = (Affine<Fq2>*)p2;
+        HK_HIP(hipMemcpy(pk->consts_g1 + 0, a_g, g1, h2d_kind(a_g)));
+        HK_HIP(hipMemcpy(pk->consts_g1 + 1, d->alpha_g, g1, h2d_kind(d->alpha_g)));
+        HK_HIP(hipMemcpy(pk->consts_g1 + 2, b_g, g1, h2d_kind(b_g)));
+        HK_HIP(hipMemcpy(pk->consts_g1 + 3, d->beta_g, g1, h2d_kind(d->beta_g)));
+        HK_HIP(hipMemcpy(pk->consts_g2 + 0, b_h, g2, h2d_kind(b_h)));
+        HK_HIP(hipMemcpy(pk->consts_g2 + 1, d->beta_h, g2, h2d_kind(d->beta_h)));
+    }
+    // --- QAP: matrices + H-query in bit-reversed order
+    if (d->A && d->B && d->C) {
+        if (d->A->n_rows != d->n_constraints || d->B->n_rows != d->n_constraints ||
+            d->C->n_rows != d->n_constraints)
+            return fail(HK_ERR_LEN);
+        pk->log_m = QapHost<C>::domain_log(d->n_constraints, d->n_inst);
+        if (pk->log_m > C::TWO_ADICITY) return fail(HK_ERR_DOMAIN_TOO_LARGE);
+        size_t m = (size_t)1 << pk->log_m;
+        if (d->h_len + 1 != m) return fail(HK_ERR_LEN);                 // prover.rs:128 assert
+        const hk_csr* Ms[3] = {d->A, d->B, d->C};
+        for (int i = 0; i < 3; i++) {
+            void *rp, *cl, *vl;
+            HK_HIP(hipMalloc(&rp, 8 * (Ms[i]->n_rows + 1))); pk->owned.push_back(rp);
+            HK_HIP(hipMalloc(&cl, 4 * Ms[i]->nnz + 16)); pk->owned.push_back(cl);
+            HK_HIP(hipMalloc(&vl, sizeof(Fr) * Ms[i]->nnz + 16)); pk->owned.push_back(vl);
+            HK_HIP(hipMemcpy(rp, Ms[i]->row_ptr, 8 * (Ms[i]->n_rows + 1), h2d_kind(Ms[i]->row_ptr)));
+            if (Ms[i]->nnz) {
+                HK_HIP(hipMemcpy(cl, Ms[i]->col, 4 * Ms[i]->nnz, h2d_kind(Ms[i]->col)));
+                HK_HIP(hipMemcpy(vl, Ms[i]->val_mont, sizeof(Fr) * Ms[i]->nnz, h2d_kind(Ms[i]->val_mont)));
+            }
+            pk->csr[i] = {(const u64*)rp, (const u32*)cl, vl, Ms[i]->n_rows, Ms[i]->nnz};
+            pk->bytes += 8 * (Ms[i]->n_rows + 1) + (4 + sizeof(Fr)) * Ms[i]->nnz;
+        }
+        pk->plan_h = make_plan(m);
+        if ((st = pk_alloc_table(pk->owned, pk->bytes, pk->plan_h.F, m, &pk->h_tab)) != HK_OK) return fail(st);
+        const Affine<Fq>* src = (const Affine<Fq>*)d->h_g;
+        void* tmp = nullptr;
+        if (!is_device_ptr(d->h_g)) {
+            HK_HIP(hipMalloc(&tmp, g1 * (d->h_len ? d->h_len : 1)));
+            HK_HIP(hipMemcpy(tmp, d->h_g, g1 * d->h_len, hipMemcpyHostToDevice));
+            src = (const Affine<Fq>*)tmp;
+        }
+        hipLaunchKernelGGL((k_pk_bitrev_copy<Fq>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s0, pk->h_tab,
+                           src, (u32)d->h_len, pk->log_m);
+        HK_HIP(hipDeviceSynchronize());
+        if (tmp) HK_HIP(hipFree(tmp));
+        HK_TRY(MsmRun<Fq>::build_tables(s0, pk->h_tab, (u32)m, pk->plan_h.F, pk->plan_h.c * pk->plan_h.WP));
+        NttTables* T;
+        HK_TRY(NttHost<C>::ensure(ctx, pk->log_m, &T));
+        pk->has_qap = true;
+    }
+    HK_HIP(hipDeviceSynchronize());
+    *out = h;
+    return HK_OK;
+}
+
+template <class C>
+void Ops<C>::pk_free(hk_pk* h) {
+    if (!h) return;
+    PkImpl<C>* pk = (PkImpl<C>*)h->impl;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : pk->owned) (void)hipFree(p);
+    delete pk;
+    delete h;
+}
+
+template <class C>
+void Ops<C>::ctx_release(hk_ctx* ctx) {
+    if (!ctx->ntt) return;
+    NttTables* T = ctx->ntt;
+    for (void* p : {T->tw_fwd, T->tw_inv, T->pw_g, T->pw_ginv})
+        if (p) (void)hipFree(p);
+    for (void* p : T->retired) (void)hipFree(p);
+    delete T;
+    ctx->ntt = nullptr;
+}
+
+// ---- small device helpers for the fused calls -------------------------------------------------------------
+// ext[0] = r, ext[1] = s, ext[2] = r*s, ext[3+i] = kappa_i   (all Montgomery)
+template <class Fr>
+__global__ void k_prep_ext(Fr* __restrict__ ext, const Fr* __restrict__ rs_kappas, u32 n_kappas) {
+    if (blockIdx.x || threadIdx.x) return;
+    Fr r = fr_load(&rs_kappas[0]), s = fr_load(&rs_kappas[1]);
+    fr_store(&ext[0], r);
+    fr_store(&ext[1], s);
+    fr_store(&ext[2], Fr::mul(r, s));
+    for (u32 i = 0; i < n_kappas; i++) fr_store(&ext[3 + i], fr_load(&rs_kappas[2 + i]));
+}
+
+// Finish: A = MA + a_g[0] + alpha_g ; B = MB2 + b_h[0] + beta_h ; B1 = MB1 + b_g[0] + beta_g ;
+//         C = s*A + r*B1 + ML' + MH   with ML' = L - rs*delta_g - sum kappa_i*delta_i   (see file header)
+// (prover.rs:135-155 "Finish C" + into_affine, committer.rs:112-114).  One lane per output point.
+template <class Fr, class Fq, class Fq2>
+__global__ void k_finish(const XYZZ<Fq>* __restrict__ res_g1,   // MA, MB1, ML, MH
+                         const XYZZ<Fq2>* __restrict__ res_g2,  // MB2
+                         const Affine<Fq>* __restrict__ c1, const Affine<Fq2>* __restrict__ c2,
+                         const Fr* __restrict__ rs,              // r, s (Montgomery)
+                         Affine<Fq>* __restrict__ out_a, Affine<Fq2>* __restrict__ out_b,
+                         Affine<Fq>* __restrict__ out_c) {
+    if (threadIdx.x) return;
+    if (blockIdx.x == 0) {
+        XYZZ<Fq> A = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[0]), ld_vec(&c1[0])), ld_vec(&c1[1]));
+        st_vec(out_a, ec_to_affine(A));
+    } else if (blockIdx.x == 1) {
+        XYZZ<Fq2> B = ec_madd_ni(ec_madd_ni(ld_vec(&res_g2[0]), ld_vec(&c2[0])), ld_vec(&c2[1]));
+        st_vec(out_b, ec_to_affine(B));
+    } else {
+        XYZZ<Fq> A = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[0]), ld_vec(&c1[0])), ld_vec(&c1[1]));
+        XYZZ<Fq> B1 = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[1]), ld_vec(&c1[2])), ld_vec(&c1[3]));
+        Fr r = Fr::from_mont(fr_load(&rs[0])), s = Fr::from_mont(fr_load(&rs[1]));
+        XYZZ<Fq> Cc = ec_mul_limbs(A, s.v);
+        Cc = ec_add_ni(Cc, ec_mul_limbs(B1, r.v));
+        Cc = ec_add_ni(Cc, ld_vec(&res_g1[2]));
+        Cc = ec_add_ni(Cc, ld_vec(&res_g1[3]));
+        st_vec(out_c, ec_to_affine(Cc));
+    }
+}
+
+static inline float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return 0.f; }
+    return ms;
+}
+
+template <class C>
+hk_status Ops<C>::commit(hk_ctx* ctx, const hk_pk* h, size_t stage, const void* w, size_t n,
+                         const void* kappa, void* out) {
+    PkImpl<C>* pk = (PkImpl<C>*)h->impl;
+    if (stage >= pk->n_stages) return HK_ERR_ARG;          // "no more values left in committing key"
+    if (n + 1 != pk->ck_n[stage]) return HK_ERR_LEN;       // committer.rs:83
+    if (n && !w) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    const MsmPlan& p = pk->plan_ck[stage];
+    size_t need = al256((n + 1) * sizeof(Fr)) + msm_sort_bytes(p) + msm_run_bytes<Fq>(p) + 4096;
+    HK_TRY(L->reserve(need));
+    hipStream_t s = L->stream;
+    bool prof = ctx->profiling;
+    if (prof) HK_HIP(hipEventRecord(L->ev[0], s));
+    Fr* sc = L->alloc_n<Fr>(n + 1);
+    if (!sc) return HK_ERR_NOMEM;
+    if (n) HK_HIP(hipMemcpyAsync(sc, w, n * sizeof(Fr), h2d_kind(w), s));
+    HK_HIP(hipMemcpyAsync(sc + n, kappa, sizeof(Fr), hipMemcpyHostToDevice, s));
+    SortBufs sb;
+    HK_TRY(MsmSort<Fr>::alloc(L, p, &sb));
+    typename MsmRun<Fq>::Bufs rb;
+    HK_TRY(MsmRun<Fq>::alloc(L, p, &rb));
+    XYZZ<Fq>* res = L->alloc_n<XYZZ<Fq>>(1);
+    Affine<Fq>* aff = L->alloc_n<Affine<Fq>>(1);
+    if (!res || !aff) return HK_ERR_NOMEM;
+    HK_TRY(MsmSort<Fr>::run(L, p, (const u32*)sc, 1, sb));
+    HK_TRY(MsmRun<Fq>::run(L, p, pk->ck_tab[stage], (u32)(n + 1), 0, sb, rb, res, nullptr, nullptr));
+    HK_TRY(MsmRun<Fq>::to_affine(s, res, aff, 1));
+    HK_HIP(hipMemcpyAsync(out, aff, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
+    if (prof) HK_HIP(hipEventRecord(L->ev[1], s));
+    HK_HIP(hipStreamSynchronize(s));
+    if (prof) {
+        memset(&L->timings, 0, sizeof(L->timings));
+        L->timings.total_ms = ev_ms(L->ev[0], L->ev[1]);
+    }
+    return HK_OK;
+}
+
+template <class C>
+hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, const void* r_m,
+                        const void* s_m, const void* kappas, size_t n_kappas, void* out_a, void* out_b,
+                        void* out_c) {
+    typedef QapHost<C> Q;
+    PkImpl<C>* pk = (PkImpl<C>*)h->impl;
+    if (!pk->has_qap) return HK_ERR_ARG;
+    if (n_v != pk->n_v) return HK_ERR_LEN;
+    if (n_kappas + 1 != pk->n_stages) return HK_ERR_LEN;   // committer.rs:112 assert
+    if (n_kappas && !kappas) return HK_ERR_ARG;
+    NttTables* T;
+    HK_TRY(NttHost<C>::ensure(ctx, pk->log_m, &T));
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    const MsmPlan &pz = pk->plan_z, &ph = pk->plan_h;
+    size_t m = (size_t)1 << pk->log_m;
+    size_t need = al256(sizeof(Fr) * pk->n_ext) + al256(sizeof(Fr) * n_v) + msm_sort_bytes(pz) +
+                  msm_sort_bytes(ph) + msm_run_bytes<Fq>(pz) + msm_run_bytes<Fq>(ph) +
+                  msm_run_bytes<Fq2>(pz) + al256(3 * m * sizeof(Fr)) + 16384;
+    HK_TRY(L->reserve(need));
+    hipStream_t s = L->stream;
+    bool prof = ctx->profiling;
+    hipEvent_t* ev = L->ev;
+    int e = 0;
+    auto mark = [&]() -> hk_status { if (prof) HK_HIP(hipEventRecord(ev[e], s)); e++; return HK_OK; };
+    HK_TRY(mark());                                                            // ev0
+    // --- extended scalar vector: z[1..] | r | s | rs | kappas
+    Fr* zext = L->alloc_n<Fr>(pk->n_ext);
+    Fr* small = L->alloc_n<Fr>(2 + n_kappas);
+    if (!zext || !small) return HK_ERR_NOMEM;
+    const Fr* zd;
+    if (is_device_ptr(z)) zd = (const Fr*)z;
+    else {
+        Fr* t = L->alloc_n<Fr>(n_v);
+        if (!t) return HK_ERR_NOMEM;
+        HK_HIP(hipMemcpyAsync(t, z, n_v * sizeof(Fr), hipMemcpyHostToDevice, s));
+        zd = t;
+    }
+    if (n_v > 1) HK_HIP(hipMemcpyAsync(zext, zd + 1, (n_v - 1) * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+    HK_HIP(hipMemcpyAsync(small, r_m, sizeof(Fr), hipMemcpyHostToDevice, s));
+    HK_HIP(hipMemcpyAsync(small + 1, s_m, sizeof(Fr), hipMemcpyHostToDevice, s));
+    if (n_kappas) HK_HIP(hipMemcpyAsync(small + 2, kappas, n_kappas * sizeof(Fr), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((k_prep_ext<Fr>), dim3(1), dim3(64), 0, s, zext + (n_v - 1), small, (u32)n_kappas);
+    // --- one digit sort shared by the four assignment-indexed queries
+    SortBufs sb, sbh;
+    HK_TRY(MsmSort<Fr>::alloc(L, pz, &sb));
+    HK_TRY(MsmSort<Fr>::alloc(L, ph, &sbh));
+    typename MsmRun<Fq>::Bufs rb1, rbh;
+    typename MsmRun<Fq2>::Bufs rb2;
+    HK_TRY(MsmRun<Fq>::alloc(L, pz, &rb1));
+    HK_TRY(MsmRun<Fq>::alloc(L, ph, &rbh));
+    HK_TRY(MsmRun<Fq2>::alloc(L, pz, &rb2));
+    XYZZ<Fq>* res1 = L->alloc_n<XYZZ<Fq>>(4);
+    XYZZ<Fq2>* res2 = L->alloc_n<XYZZ<Fq2>>(1);
+    Affine<Fq>* oa = L->alloc_n<Affine<Fq>>(2);
+    Affine<Fq2>* ob = L->alloc_n<Affine<Fq2>>(1);
+    Fr* abc = L->alloc_n<Fr>(3 * m);
+    if (!res1 || !res2 || !oa || !ob || !abc) return HK_ERR_NOMEM;
+    HK_TRY(MsmSort<Fr>::run(L, pz, (const u32*)zext, 1, sb));
+    HK_TRY(mark());                                                            // ev1: digits done
+    hipEvent_t ka0 = prof ? ev[10] : nullptr, ka1 = prof ? ev[11] : nullptr;
+    HK_TRY(MsmRun<Fq>::run(L, pz, pk->a_tab, pk->n_ext, 0, sb, rb1, res1 + 0, ka0, ka1));
+    HK_TRY(mark());                                                            // ev2: A
+    HK_TRY(MsmRun<Fq>::run(L, pz, pk->b1_tab, pk->n_ext, 0, sb, rb1, res1 + 1, nullptr, nullptr));
+    HK_TRY(mark());                                                            // ev3: B1
+    HK_TRY(MsmRun<Fq2>::run(L, pz, pk->b2_tab, pk->n_ext, 0, sb, rb2, res2, nullptr, nullptr));
+    HK_TRY(mark());                                                            // ev4: B2
+    HK_TRY(MsmRun<Fq>::run(L, pz, pk->l_tab, pk->l_n, pk->l_off, sb, rb1, res1 + 2, nullptr, nullptr));
+    HK_TRY(mark());                                                            // ev5: L
+    // --- quotient polynomial h (bit-reversed order, matching h_tab)
+    HK_TRY(Q::run(s, T, pk->csr[0], pk->csr[1], pk->csr[2], pk->n_inst, pk->n_c, zd, abc, pk->log_m));
+    HK_TRY(mark());                                                            // ev6: witness map
+    HK_TRY(MsmSort<Fr>::run(L, ph, (const u32*)abc, 1, sbh));
+    hipEvent_t kh0 = prof ? ev[12] : nullptr, kh1 = prof ? ev[13] : nullptr;
+    HK_TRY(MsmRun<Fq>::run(L, ph, pk->h_tab, (u32)m, 0, sbh, rbh, res1 + 3, kh0, kh1));
+    HK_TRY(mark());                                                            // ev7: H
+    hipLaunchKernelGGL((k_finish<Fr, Fq, Fq2>), dim3(3), dim3(64), 0, s, res1, res2, pk->consts_g1,
+                       pk->consts_g2, small, oa, ob, oa + 1);
+    HK_HIP(hipGetLastError());
+    HK_HIP(hipMemcpyAsync(out_a, oa, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
+    HK_HIP(hipMemcpyAsync(out_b, ob, sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, s));
+    HK_HIP(hipMemcpyAsync(out_c, oa + 1, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
+    HK_TRY(mark());                                                            // ev8: finish
+    HK_HIP(hipStreamSynchronize(s));
+    if (prof) {
+        hk_timings& t = L->timings;
+        memset(&t, 0, sizeof(t));
+        t.total_ms = ev_ms(ev[0], ev[8]);
+        t.digits_ms = ev_ms(ev[0], ev[1]);
+        t.msm_a_ms = ev_ms(ev[1], ev[2]);
+        t.msm_b_g1_ms = ev_ms(ev[2], ev[3]);
+        t.msm_b_g2_ms = ev_ms(ev[3], ev[4]);
+        t.msm_l_ms = ev_ms(ev[4], ev[5]);
+        t.witness_map_ms = ev_ms(ev[5], ev[6]);
+        t.msm_h_ms = ev_ms(ev[6], ev[7]);
+        t.finish_ms = ev_ms(ev[7], ev[8]);
+        t.accum_kernel_ms = ev_ms(ev[12], ev[13]);          // H-query bucket accumulation (dominant kernel)
+        t.accum_kernel_launches = 1;
+    }
+    return HK_OK;
+}
+
+}  // namespace hk
