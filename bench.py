@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — subcircuit Groth16 proofs/sec on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic subcircuits per GPU: for every
+subcircuit one stage-0 commit (hk_commit) and one stage-1 prove (hk_prove), exactly the unit of work
+`process_stage0_request` / `process_stage1_request` do in the reference
+(distributed-prover/src/worker.rs:91-146,150-195).  Subcircuits are sharded contiguously over ranks
+(mpi-snark/src/bin/node.rs:471-472,490-493); there is no data-path collective (weak scaling: every
+GPU proves `--subcircuits` of them per step).  Inputs (proving key with shift tables, matrices,
+assignments) are resident in HBM before the timed region; outputs are 3 affine points per proof.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="big-merkle-64x32",
+                    help="workload (hekaton_system_amd/workload.py CONFIGS); default = BASELINE configs[1]")
+    ap.add_argument("--curve", default="bn254", help="bn254 is what the reference instantiates (SURVEY F1)")
+    ap.add_argument("--subcircuits", type=int, default=8, help="subcircuits per GPU per step")
+    ap.add_argument("--threads", type=int, default=4, help="host threads (= GPU lanes) proving concurrently")
+    ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, circ, pk_host, fc):
+    """The CPU restatement of the ark-ec/ark-poly path (oracle/c, kind "port") timed on this box's
+    host cores over ONE subcircuit of the same workload (commit + prove)."""
+    import shutil
+    import tempfile
+    from oracle import c_oracle
+    lib = None
+    if shutil.which("g++"):
+        try:
+            lib = c_oracle.build(native=True, out=os.path.join(tempfile.mkdtemp(prefix="hk_oracle_"), "libhk_oracle.so"))
+        except Exception as e:       # noqa: BLE001
+            log("native oracle build failed, using prebuilt:", e)
+    co = c_oracle.COracle(args.curve, lib_path=lib)
+    cores = co.threads()
+    view = co.pk_view(**pk_host["points"])
+    A, B, C = pk_host["matrices"]
+    circ.set_witness_seed(1)
+    z = circ.full_assignment_bytes()
+    w0 = circ.stage0_witness_bytes()
+    kap = fc.enc([7])
+    t0 = time.time()
+    co.commit(view, 0, w0, kap)
+    co.prove(view, A, B, C, circ.N_INST, circ.n_c, z, fc.enc1(11), fc.enc1(13), kap)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "1 subcircuit (1 commit + 1 prove) of %s, %.1f s" % (args.config, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    from hekaton_system_amd import capi
+    from hekaton_system_amd.cp_groth16 import FrCodec, SeededRng, generate_parameters
+    from hekaton_system_amd.workload import make_config
+
+    dev = local_rank
+    ctx = capi.Context(args.curve, dev)
+    fc = FrCodec(args.curve)
+    circ = make_config(args.curve, args.config)
+    log("rank %d: setup %s n_c=%d n_v=%d" % (rank, args.config, circ.n_c, circ.n_v))
+    t0 = time.time()
+    keep_host = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    pk, td = generate_parameters(circ, args.curve, SeededRng(b"HEKATON1" * 4), ctx, keep_on_device=not keep_host)
+    dpk = pk.upload(ctx)
+    pk_host = None
+    if keep_host:
+        pk_host = {"points": dict(a_g=pk.a_g, b_g=pk.b_g, b_h=pk.b_h, h_g=pk.h_g, ck_stages=pk.ck.deltas_abc_g,
+                                  deltas_g=pk.deltas_g, last_delta_h=pk.vk.last_delta_h, alpha_g=pk.vk.alpha_g,
+                                  beta_g=pk.beta_g, beta_h=pk.vk.beta_h),
+                   "matrices": pk.matrices}
+    else:
+        for b in (pk.a_g, pk.b_g, pk.b_h, pk.h_g):
+            if isinstance(b, capi.DeviceBuffer):
+                b.free()
+    log("rank %d: key generated + resident in %.1f s" % (rank, time.time() - t0))
+    # assignments resident in HBM
+    zs, w0s = [], []
+    for k in range(args.witnesses):
+        circ.set_witness_seed(1000 * rank + k + 1)
+        zs.append(capi.DeviceBuffer.from_host(ctx, circ.full_assignment_bytes()))
+        w0s.append(capi.DeviceBuffer.from_host(ctx, circ.stage0_witness_bytes()))
+    r_b, s_b, kap = fc.enc1(0x1234567), fc.enc1(0x7654321), fc.enc([0x5555])
+    ctx.set_profiling(True)
+    accum_ms, phase = [], {}
+
+    def one(i):
+        k = i % args.witnesses
+        dpk.commit(0, w0s[k], kap, n=circ.n0)
+        out = dpk.prove(zs[k], r_b, s_b, kap, n_v=circ.n_v)
+        return out, ctx.last_timings()
+
+    pool = ThreadPoolExecutor(max_workers=args.threads)
+
+    def step(record):
+        res = list(pool.map(one, range(args.subcircuits)))
+        if record:
+            for _, t in res:
+                accum_ms.append(t["accum_kernel_ms"])
+                for key, v in t.items():
+                    phase[key] = phase.get(key, 0.0) + v
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        last = step(True)
+    ctx.sync()
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    proofs = world * args.subcircuits * args.steps
+    if rank == 0:
+        m = 1
+        while m < circ.n_c + circ.N_INST:
+            m *= 2
+        g1 = ctx.g1_bytes
+        # dominant kernel = bucket accumulation of the H query: algorithmic bytes per launch
+        # = (m-1) * (32 + S1)  (SURVEY.md §8d "MSM-G1 = n*(32+S1)")
+        alg_bytes = (m - 1) * (32 + g1)
+        avg_ms = float(np.mean(accum_ms)) if accum_ms else float("nan")
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        nprov = max(1, len(accum_ms))
+        out = {
+            "metric": "subcircuit Groth16 proofs/sec (whole node), big-merkle",
+            "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (Montgomery mod-p integers)",
+            "data": "synthetic (SHA-like 85%% small / 15%% full-width witnesses, genuine Groth16 SRS from a "
+                    "seeded trapdoor; %d distinct assignments cycled)" % args.witnesses,
+            "config": {"workload": args.config, "curve": args.curve, "subcircuits_per_gpu_per_step": args.subcircuits,
+                       "n_constraints": circ.n_c, "n_variables": circ.n_v, "domain": m,
+                       "host_threads_per_gpu": args.threads, "sharding": "subcircuits/%d per rank" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accum0<Fq> (H-query bucket accumulation)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms},
+            "phase_ms_per_proof": {k: v / nprov for k, v in phase.items() if k.endswith("_ms")},
+        }
+        if keep_host:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, circ, pk_host, fc)
+            except Exception as e:       # noqa: BLE001
+                log("cpu baseline failed:", e)
+                out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,7 @@ class hk_timings(C.Structure):
 EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk_ctx_sync",
            "hk_ctx_set_profiling", "hk_ctx_last_timings", "hk_ctx_sizes", "hk_dev_alloc", "hk_dev_free",
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
-           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove"]
+           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2"]
 
 _lib = None
 
@@ -86,6 +86,8 @@ def load():
     for f in (lib.hk_msm_g1, lib.hk_msm_g2):
         f.argtypes = [vp, vp, sz, vp, sz, i, i, vp]
     lib.hk_ntt.argtypes = [vp, vp, C.c_uint, i, i]
+    for f in (lib.hk_fixed_base_g1, lib.hk_fixed_base_g2):
+        f.argtypes = [vp, vp, vp, sz, i, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -203,6 +205,17 @@ class Context:
         ns = n_scalars if n_scalars is not None else len(scalars) // self.fr_bytes
         return self._msm(self.lib.hk_msm_g2, self.g2_bytes, bases, nb, scalars, ns, montgomery, checked)
 
+    def fixed_base(self, group, base, scalars, n=None, montgomery=True, out=None):
+        """FixedBase::msm + normalize_batch (generator.rs:134-224): out[i] = scalars[i] * base.
+        `out` may be a DeviceBuffer (stays in HBM); otherwise a numpy array is returned."""
+        pb = self.g1_bytes if group == 1 else self.g2_bytes
+        n = n if n is not None else len(scalars) // self.fr_bytes
+        fn = self.lib.hk_fixed_base_g1 if group == 1 else self.lib.hk_fixed_base_g2
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        res = out if out is not None else np.zeros(n * pb, dtype=np.uint8)
+        check(fn(self.handle, base.ctypes.data, ptr(scalars), n, int(montgomery), ptr(res)), fn.__name__)
+        return res
+
     def ntt(self, data, log_m, inverse=False, coset=False):
         """In-place on `data` (numpy uint8 array of 2^log_m Fr or a DeviceBuffer)."""
         check(self.lib.hk_ntt(self.handle, ptr(data), int(log_m), int(inverse), int(coset)), "hk_ntt")
@@ -235,19 +248,25 @@ class Context:
         """hk_pk_upload: all arguments packed-affine numpy uint8 arrays (or DeviceBuffers with explicit
         lengths via (buf, n) tuples).  matrices = (A, B, C) CSR triples as in witness_map."""
         def arr(x):
-            return np.ascontiguousarray(x, dtype=np.uint8)
+            return x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8)
+
+        def addr(x):
+            return x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data
+
+        def nbytes(x):
+            return x.nbytes
         keep = []
         d = hk_pk_desc()
         a_g, b_g, b_h, h_g = arr(a_g), arr(b_g), arr(b_h), arr(h_g)
         keep += [a_g, b_g, b_h, h_g]
-        d.a_g, d.a_len = a_g.ctypes.data, len(a_g) // self.g1_bytes
-        d.b_g, d.b_g_len = b_g.ctypes.data, len(b_g) // self.g1_bytes
-        d.b_h, d.b_h_len = b_h.ctypes.data, len(b_h) // self.g2_bytes
-        d.h_g, d.h_len = h_g.ctypes.data, len(h_g) // self.g1_bytes
+        d.a_g, d.a_len = addr(a_g), nbytes(a_g) // self.g1_bytes
+        d.b_g, d.b_g_len = addr(b_g), nbytes(b_g) // self.g1_bytes
+        d.b_h, d.b_h_len = addr(b_h), nbytes(b_h) // self.g2_bytes
+        d.h_g, d.h_len = addr(h_g), nbytes(h_g) // self.g1_bytes
         cks = [arr(c) for c in ck_stages]
         keep += cks
-        ck_ptrs = (C.c_void_p * len(cks))(*[c.ctypes.data for c in cks])
-        ck_lens = (C.c_size_t * len(cks))(*[len(c) // self.g1_bytes for c in cks])
+        ck_ptrs = (C.c_void_p * len(cks))(*[addr(c) for c in cks])
+        ck_lens = (C.c_size_t * len(cks))(*[nbytes(c) // self.g1_bytes for c in cks])
         d.ck_stage, d.ck_len, d.n_stages = ck_ptrs, ck_lens, len(cks)
         small = [arr(x) for x in (deltas_g, last_delta_h, alpha_g, beta_g, beta_h)]
         keep += small

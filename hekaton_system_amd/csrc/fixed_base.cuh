@@ -1,0 +1,90 @@
+// fixed_base.cuh — fixed-base batch scalar multiplication  out[i] = scalars[i] * base  on the device.
+//
+// Replaces ark-ec `FixedBase::{get_window_table, msm}` + `CurveGroup::normalize_batch` as used by the
+// reference's trusted setup (cp-groth16/src/generator.rs:126-224: a_g, b_g, b_h, h_g, deltas_abc_g,
+// gamma_abc_g, deltas_g are all "scalar vector times one generator").  SURVEY.md §8(f) row 3; it is
+// also how tests and bench.py build genuine Groth16 SRSs at full size without touching the oracle.
+//
+// 8-bit windows: table[w][j] = j * 2^(8w) * base (affine), one mixed add per non-zero byte of the
+// scalar; results are normalised with Montgomery's batch-inversion trick, 16 points per lane.
+#pragma once
+#include "msm.cuh"
+
+namespace hk {
+
+constexpr int FB_WINDOWS = 32;       // 256-bit scalars
+constexpr int FB_CHUNK = 16;         // points per lane in the batch normalisation
+
+#if defined(__HIPCC__)
+
+// table[w * 256 + j] = j * 2^(8w) * base ; one lane per entry (setup cost only)
+template <class F>
+__global__ void __launch_bounds__(64)
+k_fb_table(const Affine<F>* __restrict__ base, Affine<F>* __restrict__ table) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= FB_WINDOWS * 256) return;
+    u32 w = t >> 8, j = t & 255;
+    XYZZ<F> p = XYZZ<F>::from_affine(ld_vec(base));
+    for (u32 k = 0; k < 8 * w; k++) p = ec_dbl_ni(p);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 7; bit >= 0; bit--) {
+        acc = ec_dbl_ni(acc);
+        if ((j >> bit) & 1) acc = ec_add_ni(acc, p);
+    }
+    st_vec(&table[t], ec_to_affine(acc));
+}
+
+template <class Fr, class F>
+__global__ void __launch_bounds__(64)
+k_fb_mul(const Affine<F>* __restrict__ table, const Fr* __restrict__ scalars, int is_mont, u32 n,
+         XYZZ<F>* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s;
+    const uint4* src = reinterpret_cast<const uint4*>(scalars + i);
+#pragma unroll
+    for (int k = 0; k < Fr::N / 4; k++) {
+        uint4 v = src[k];
+        s.v[4 * k] = v.x; s.v[4 * k + 1] = v.y; s.v[4 * k + 2] = v.z; s.v[4 * k + 3] = v.w;
+    }
+    if (is_mont) s = Fr::from_mont(s);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (u32 w = 0; w < (u32)FB_WINDOWS; w++) {
+        u32 d = (s.v[w >> 2] >> (8 * (w & 3))) & 255u;
+        if (d) acc = ec_madd(acc, ld_vec(&table[w * 256 + d]));
+    }
+    st_vec(&out[i], acc);
+}
+
+// XYZZ -> affine for n points, FB_CHUNK per lane, one field inversion per lane.
+// scratch: n coordinate-field elements (prefix products of zzz).
+template <class F>
+__global__ void __launch_bounds__(64)
+k_batch_affine(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, F* __restrict__ scratch, u32 n) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 lo = t * FB_CHUNK;
+    if (lo >= n) return;
+    u32 hi = min(lo + (u32)FB_CHUNK, n);
+    F acc = F::one();
+    for (u32 i = lo; i < hi; i++) {
+        st_vec(&scratch[i], acc);
+        F zzz = ld_vec(&in[i].zzz);
+        if (!zzz.is_zero()) acc = f_mul_ni(acc, zzz);
+    }
+    F inv = fp_inv(acc);
+    for (u32 i = hi; i-- > lo;) {
+        XYZZ<F> p = ld_vec(&in[i]);
+        if (p.is_inf()) { st_vec(&out[i], Affine<F>::inf()); continue; }
+        F zzz_inv = f_mul_ni(inv, ld_vec(&scratch[i]));
+        inv = f_mul_ni(inv, p.zzz);
+        F zz_inv = f_mul_ni(f_mul_ni(zzz_inv, zzz_inv), f_mul_ni(p.zz, p.zz));
+        Affine<F> a;
+        a.x = f_mul_ni(p.x, zz_inv);
+        a.y = f_mul_ni(p.y, zzz_inv);
+        st_vec(&out[i], a);
+    }
+}
+
+#endif
+
+}  // namespace hk

@@ -3,6 +3,8 @@
 
 namespace hk {
 
+static thread_local hk_timings tl_last_timings = {};
+
 hk_status Lane::reserve(size_t bytes) {
     arena_off = 0;
     if (bytes <= arena_cap) return HK_OK;
@@ -49,6 +51,7 @@ LaneGuard::~LaneGuard() {
     std::unique_lock<std::mutex> lk(ctx->mu);
     lane->busy = false;
     ctx->last = lane->timings;
+    tl_last_timings = lane->timings;
     lk.unlock();
     ctx->cv.notify_one();
 }
@@ -152,8 +155,7 @@ hk_status hk_ctx_set_profiling(hk_ctx* ctx, int enable) {
 
 hk_status hk_ctx_last_timings(hk_ctx* ctx, hk_timings* out) {
     if (!ctx || !out) return HK_ERR_ARG;
-    std::unique_lock<std::mutex> lk(ctx->mu);
-    *out = ctx->last;
+    *out = hk::tl_last_timings;        // timings of the calling thread's most recent call
     return HK_OK;
 }
 
@@ -201,6 +203,14 @@ hk_status hk_msm_g2(hk_ctx* ctx, const void* bases, size_t n_bases, const void* 
                     int mont, int checked, void* out) {
     if (!ctx || !out) return HK_ERR_ARG;
     return ctx->ops->msm(ctx, 2, bases, n_bases, scalars, n_scalars, mont, checked, out);
+}
+hk_status hk_fixed_base_g1(hk_ctx* ctx, const void* base, const void* scalars, size_t n, int mont, void* out) {
+    if (!ctx || !base || (n && (!scalars || !out))) return HK_ERR_ARG;
+    return ctx->ops->fixed_base(ctx, 1, base, scalars, n, mont, out);
+}
+hk_status hk_fixed_base_g2(hk_ctx* ctx, const void* base, const void* scalars, size_t n, int mont, void* out) {
+    if (!ctx || !base || (n && (!scalars || !out))) return HK_ERR_ARG;
+    return ctx->ops->fixed_base(ctx, 2, base, scalars, n, mont, out);
 }
 hk_status hk_ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int coset) {
     if (!ctx || !data) return HK_ERR_ARG;

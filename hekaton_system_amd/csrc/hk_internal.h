@@ -51,6 +51,13 @@ struct CurveBls381 {
     static constexpr u32 GEN_INV[8] = HK_BLS12_381_FR_GEN_INV;
 };
 
+// scalar field that goes with a coordinate field
+template <class F> struct ScalarOf;
+template <> struct ScalarOf<CurveBn254::Fq> { typedef CurveBn254::Fr type; };
+template <> struct ScalarOf<CurveBn254::Fq2> { typedef CurveBn254::Fr type; };
+template <> struct ScalarOf<CurveBls381::Fq> { typedef CurveBls381::Fr type; };
+template <> struct ScalarOf<CurveBls381::Fq2> { typedef CurveBls381::Fr type; };
+
 // ---- per-call lane: one stream + one grow-only scratch arena ---------------------------------------
 struct Lane {
     hipStream_t stream = nullptr;
@@ -93,6 +100,8 @@ struct CurveOps {
     hk_status (*prove)(hk_ctx*, const hk_pk*, const void* z, size_t n_v, const void* r, const void* s,
                        const void* kappas, size_t n_kappas, void* a, void* b, void* c);
     void (*ctx_release)(hk_ctx*);
+    hk_status (*fixed_base)(hk_ctx*, int group, const void* base, const void* scalars, size_t n, int mont,
+                            void* out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

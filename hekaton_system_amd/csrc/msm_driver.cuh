@@ -39,6 +39,11 @@ struct MsmRun {
                          hipEvent_t ev0, hipEvent_t ev1);
     static hk_status build_tables(hipStream_t s, Affine<F>* table, u32 n, u32 groups, u32 shift_bits);
     static hk_status to_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, u32 n);
+    // fixed-base batch scalar multiplication (fixed_base.cuh); all pointers device.
+    // table: 32*256 affine scratch, xy: n XYZZ scratch, pref: n field-element scratch
+    static hk_status fixed_base(hipStream_t s, const Affine<F>* base, const void* scalars, int is_mont,
+                                u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out);
+    static hk_status batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, F* pref, u32 n);
 };
 
 }  // namespace hk

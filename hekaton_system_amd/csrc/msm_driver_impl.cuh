@@ -1,6 +1,7 @@
 // msm_driver_impl.cuh — definitions for msm_driver.cuh (see there).
 #pragma once
 #include "msm_driver.cuh"
+#include "fixed_base.cuh"
 
 namespace hk {
 
@@ -85,6 +86,27 @@ hk_status MsmRun<F>::to_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out,
     hipLaunchKernelGGL((k_to_affine<F>), dim3((n + 63) / 64), dim3(64), 0, s, in, out, n);
     HK_HIP(hipGetLastError());
     return HK_OK;
+}
+
+template <class F>
+hk_status MsmRun<F>::batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, F* pref, u32 n) {
+    if (n == 0) return HK_OK;
+    u32 lanes = (n + FB_CHUNK - 1) / FB_CHUNK;
+    hipLaunchKernelGGL((k_batch_affine<F>), dim3((lanes + 63) / 64), dim3(64), 0, s, in, out, pref, n);
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
+template <class F>
+hk_status MsmRun<F>::fixed_base(hipStream_t s, const Affine<F>* base, const void* scalars, int is_mont,
+                                u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out) {
+    typedef typename ScalarOf<F>::type Fr;
+    if (n == 0) return HK_OK;
+    hipLaunchKernelGGL((k_fb_table<F>), dim3(FB_WINDOWS * 256 / 64), dim3(64), 0, s, base, table);
+    hipLaunchKernelGGL((k_fb_mul<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, table, (const Fr*)scalars,
+                       is_mont, n, xy);
+    HK_HIP(hipGetLastError());
+    return batch_affine(s, xy, out, pref, n);
 }
 
 }  // namespace hk

@@ -14,6 +14,7 @@
 #include <string>
 #include "curve_ops_impl.cuh"
 #include "ntt.cuh"
+#include "fixed_base.cuh"
 
 namespace hk {
 
@@ -494,6 +495,36 @@ void Ops<C>::pk_free(hk_pk* h) {
     for (void* p : pk->owned) (void)hipFree(p);
     delete pk;
     delete h;
+}
+
+template <class C>
+hk_status Ops<C>::fixed_base(hk_ctx* ctx, int group, const void* base, const void* scalars, size_t n, int mont,
+                             void* out) {
+    if (n == 0) return HK_OK;
+    if (n >= (1u << 30)) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    auto run = [&](auto ftag) -> hk_status {
+        typedef decltype(ftag) F;
+        size_t need = al256(sizeof(Affine<F>)) + al256(n * sizeof(Fr)) + al256(sizeof(Affine<F>) * FB_WINDOWS * 256) +
+                      al256(n * sizeof(XYZZ<F>)) + al256(n * sizeof(F)) + al256(n * sizeof(Affine<F>)) + 8192;
+        HK_TRY(L->reserve(need));
+        const void *bd, *sd;
+        HK_TRY(to_device(L, base, sizeof(Affine<F>), &bd));
+        HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sd));
+        Affine<F>* table = L->alloc_n<Affine<F>>(FB_WINDOWS * 256);
+        XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
+        F* pref = L->alloc_n<F>(n);
+        bool out_dev = is_device_ptr(out);
+        Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
+        if (!table || !xy || !pref || !od) return HK_ERR_NOMEM;
+        HK_TRY(MsmRun<F>::fixed_base(L->stream, (const Affine<F>*)bd, sd, mont, (u32)n, table, xy, pref, od));
+        if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+        HK_HIP(hipStreamSynchronize(L->stream));
+        return HK_OK;
+    };
+    return group == 1 ? run(Fq()) : run(Fq2());
 }
 
 template <class C>

@@ -145,6 +145,15 @@ hk_status hk_witness_map(hk_ctx* ctx, const hk_csr* A, const hk_csr* B, const hk
                          const void* z_mont, size_t n_v,
                          void* h_out, size_t h_capacity, size_t* m_out);
 
+/* Fixed-base batch scalar multiplication: out[i] = scalars[i] * base, normalised to affine.
+ * Replaces `FixedBase::msm` + `normalize_batch` of the trusted setup (cp-groth16/src/generator.rs:
+ * 134-224).  base [h|d]: one affine point; scalars [h|d]: n Fr;
+ * out [h|d]: n packed affine points. */
+hk_status hk_fixed_base_g1(hk_ctx* ctx, const void* base, const void* scalars, size_t n,
+                           int scalars_are_montgomery, void* out);
+hk_status hk_fixed_base_g2(hk_ctx* ctx, const void* base, const void* scalars, size_t n,
+                           int scalars_are_montgomery, void* out);
+
 /* ---- proving-key residency -------------------------------------------------------------- */
 hk_status hk_pk_upload(hk_ctx* ctx, const hk_pk_desc* desc, hk_pk** out);
 void      hk_pk_free(hk_pk* pk);

@@ -1,0 +1,144 @@
+"""GPU parity at realistic sizes: the HIP path against the multi-threaded C++ oracle (bit-exact) and,
+at BASELINE.json's full size, against size-independent checks: every proof must satisfy the Groth16
+equation in the exponent under the SRS trapdoor (the pairing-free form of verifier.rs:23-43), and
+h * Z == a*b - c at a random point."""
+import random
+import time
+
+import numpy as np
+import pytest
+
+from hekaton_system_amd import capi
+from hekaton_system_amd.cp_groth16 import (FrCodec, SeededRng, generate_parameters, CommitmentBuilder,
+                                           CURVE_PARAMS)
+from hekaton_system_amd.workload import make_config, SyntheticSubcircuit
+from oracle.c_oracle import COracle
+from oracle.pyref import curve as ocurve
+from oracle.pyref.codec import Codec
+from oracle.pyref.params import CURVES
+
+pytestmark = pytest.mark.gpu
+
+
+def _trapdoor_check(cname, circ, td, z, h, comms, kappas, r_, s_, proof):
+    """Recomputes log(A), log(B), log(C), log(D_i) in Fr from the toxic waste and compares group
+    elements; also checks the verifier equation in the exponent."""
+    cp = CURVES[cname]
+    cd = Codec(cp)
+    G1, G2 = ocurve.G1(cp), ocurve.G2(cp)
+    mod = cp.r
+    inv = lambda x: pow(x, -1, mod)
+    ni, n0 = circ.N_INST, circ.n0
+    dl = td.deltas[-1]
+    az = sum(x * y for x, y in zip(z, td.a)) % mod
+    bz = sum(x * y for x, y in zip(z, td.b)) % mod
+    abc = [(td.beta * a + td.alpha * b + c) % mod for a, b, c in zip(td.a, td.b, td.c)]
+    log_a = (r_ * dl + az + td.alpha) % mod
+    log_b = (s_ * dl + bz + td.beta) % mod
+    l_log = sum(z[i] * abc[i] for i in range(ni + n0, len(z))) % mod * inv(dl) % mod
+    hsum, tp = 0, 1
+    for i in range(td.m - 1):
+        hsum += h[i] * tp
+        tp = tp * td.t % mod
+    h_log = hsum % mod * td.zt % mod * inv(dl) % mod
+    log_c = (s_ * log_a + r_ * log_b - r_ * s_ % mod * dl + l_log + h_log) % mod
+    d_logs = []
+    for k, kappa in enumerate(kappas):
+        d = sum(z[i] * abc[i] for i in range(ni, ni + n0)) % mod * inv(td.deltas[k]) % mod
+        d_logs.append((d + kappa * dl) % mod)
+        log_c = (log_c - kappa * td.deltas[k]) % mod
+    g = G1.mul(G1.gen, td.g1_scalar)
+    hh = G2.mul(G2.gen, td.g2_scalar)
+    assert cd.g1_from(proof[0]) == G1.mul(g, log_a), "A"
+    assert cd.g2_from(proof[1]) == G2.mul(hh, log_b), "B"
+    assert cd.g1_from(proof[2]) == G1.mul(g, log_c), "C"
+    for com, d in zip(comms, d_logs):
+        assert cd.g1_from(com) == G1.mul(g, d), "D"
+    ic = sum(z[i] * abc[i] for i in range(ni)) % mod * inv(td.gamma) % mod
+    lhs = log_a * log_b % mod
+    rhs = (td.alpha * td.beta + ic * td.gamma + sum(d * dk for d, dk in zip(d_logs, td.deltas)) + log_c * dl) % mod
+    assert lhs == rhs, "Groth16 equation"
+
+
+def _run_config(ctx, cname, name, check_oracle_prove):
+    fc = FrCodec(cname)
+    circ = make_config(cname, name)
+    t0 = time.time()
+    pk, td = generate_parameters(circ, cname, SeededRng(b"HEKATON1" * 4), ctx)
+    dpk = pk.upload(ctx)
+    print("setup %.1fs" % (time.time() - t0))
+    circ.set_witness_seed(77)
+    z_ints = circ.assignment_ints()
+    zb = circ.full_assignment_bytes()
+    w0 = circ.stage0_witness_bytes()
+    kappa, r_, s_ = 0x1111, 0x2222_3333_4444, 0x5555_6666
+    com = dpk.commit(0, w0, fc.enc1(kappa))
+    zdev = capi.DeviceBuffer.from_host(ctx, zb)
+    a, b, c = dpk.prove(zdev, fc.enc1(r_), fc.enc1(s_), fc.enc([kappa]), n_v=circ.n_v)
+    # independent quotient polynomial from the CPU oracle, and the GPU witness map against it bit for bit
+    co = COracle(cname)
+    A, B, C = pk.matrices
+    h_o, m = co.witness_map(A, B, C, circ.N_INST, circ.n_c, zb)
+    h_g, m2 = ctx.witness_map(A, B, C, circ.N_INST, circ.n_c, zdev, n_v=circ.n_v)
+    assert m == m2 and np.array_equal(h_o, h_g)
+    h = fc.dec(h_o)
+    assert h[-1] == 0
+    _trapdoor_check(cname, circ, td, z_ints, h, [com], [kappa], r_, s_, (a, b, c))
+    if check_oracle_prove:
+        view = co.pk_view(a_g=pk.a_g, b_g=pk.b_g, b_h=pk.b_h, h_g=pk.h_g, ck_stages=pk.ck.deltas_abc_g,
+                          deltas_g=pk.deltas_g, last_delta_h=pk.vk.last_delta_h, alpha_g=pk.vk.alpha_g,
+                          beta_g=pk.beta_g, beta_h=pk.vk.beta_h)
+        assert np.array_equal(co.commit(view, 0, w0, fc.enc1(kappa)), com)
+        oa, ob, oc = co.prove(view, A, B, C, circ.N_INST, circ.n_c, zb, fc.enc1(r_), fc.enc1(s_), fc.enc([kappa]))
+        assert np.array_equal(oa, a) and np.array_equal(ob, b) and np.array_equal(oc, c)
+    zdev.free(); dpk.free()
+
+
+def test_config0_big_merkle_4x1_bit_exact_vs_cpu_oracle(ctx_bn254):
+    """BASELINE configs[0] shape (m = 2^16): commit + prove bit-exact vs the C++ oracle, and valid."""
+    _run_config(ctx_bn254, "bn254", "big-merkle-4x1", check_oracle_prove=True)
+
+
+def test_config1_big_merkle_64x32_full_size_properties(ctx_bn254):
+    """BASELINE configs[1] shape (m = 2^21, n_v ~ 1.3e6): proof valid under the trapdoor, witness map
+    bit-exact vs the CPU oracle."""
+    _run_config(ctx_bn254, "bn254", "big-merkle-64x32", check_oracle_prove=False)
+
+
+@pytest.mark.parametrize("group,n,dense", [(1, 1 << 16, True), (1, 1 << 16, False), (2, 1 << 13, True),
+                                           (1, 100_003, True)])
+def test_msm_primitive_large_vs_cpu_oracle(group, n, dense, ctx_bn254):
+    """hk_msm_g1/g2 over caller-supplied bases (no shift tables) vs the ark-style Pippenger on the CPU."""
+    fc = FrCodec("bn254")
+    p = CURVE_PARAMS["bn254"]
+    rnd = random.Random(n + group)
+    base = fc.g1(p["g1"]) if group == 1 else fc.g2(p["g2"])
+    ks = [rnd.randrange(1, p["r"]) for _ in range(n)]
+    bases = ctx_bn254.fixed_base(group, base, fc.enc(ks))
+    scal = [rnd.randrange(p["r"]) if (dense or rnd.random() < 0.15) else rnd.randrange(2) for _ in range(n)]
+    sb = fc.enc(scal)
+    got = (ctx_bn254.msm_g1 if group == 1 else ctx_bn254.msm_g2)(bases, sb)
+    want = COracle("bn254").msm(group, bases, sb)
+    assert np.array_equal(got, want)
+    # linearity: every base is k_i * G, so the sum must be (sum s_i k_i) * G
+    tot = sum(s * k for s, k in zip(scal, ks)) % p["r"]
+    chk = ctx_bn254.fixed_base(group, base, fc.enc([tot]))
+    assert np.array_equal(got, chk)
+
+
+@pytest.mark.parametrize("log_m", [16, 20])
+def test_ntt_large_roundtrip_and_oracle(log_m, ctx_bn254):
+    fc = FrCodec("bn254")
+    rng = np.random.default_rng(log_m)
+    m = 1 << log_m
+    raw = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x0f                                  # < r
+    x = raw.ravel().copy()
+    dev = capi.DeviceBuffer.from_host(ctx_bn254, x)
+    ctx_bn254.ntt(dev, log_m, inverse=False, coset=True)
+    fwd = dev.to_host()
+    want = COracle("bn254").ntt(x.copy(), log_m, inverse=False, coset=True)
+    assert np.array_equal(fwd, want)
+    ctx_bn254.ntt(dev, log_m, inverse=True, coset=True)
+    assert np.array_equal(dev.to_host(), x)
+    dev.free()
