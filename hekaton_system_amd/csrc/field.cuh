@@ -9,6 +9,10 @@
 #pragma once
 #include <stdint.h>
 #include "hk_params.h"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HK_NO_ASM_MUL)
+#include "mont_asm.h"
+#define HK_USE_ASM_MUL 1
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -27,19 +31,20 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 // ---- parameter packs ---------------------------------------------------------------------
-#define HK_DEFINE_FIELD(NAME, PREFIX)                                        \
+#define HK_DEFINE_FIELD(NAME, PREFIX, ASMID)                                 \
     struct NAME {                                                            \
         static constexpr int N = PREFIX##_N;                                 \
+        static constexpr int ASM_ID = ASMID;                                 \
         static constexpr u32 MOD[PREFIX##_N] = PREFIX##_MOD;                 \
         static constexpr u32 ONE[PREFIX##_N] = PREFIX##_ONE;                 \
         static constexpr u32 R2[PREFIX##_N] = PREFIX##_R2;                   \
         static constexpr u32 INV = PREFIX##_INV32;                           \
     };
 
-HK_DEFINE_FIELD(Bn254FrP, HK_BN254_FR)
-HK_DEFINE_FIELD(Bn254FqP, HK_BN254_FQ)
-HK_DEFINE_FIELD(Bls381FrP, HK_BLS12_381_FR)
-HK_DEFINE_FIELD(Bls381FqP, HK_BLS12_381_FQ)
+HK_DEFINE_FIELD(Bn254FrP, HK_BN254_FR, 1)
+HK_DEFINE_FIELD(Bn254FqP, HK_BN254_FQ, 2)
+HK_DEFINE_FIELD(Bls381FrP, HK_BLS12_381_FR, 3)
+HK_DEFINE_FIELD(Bls381FqP, HK_BLS12_381_FQ, 0)      // 12 limbs: C++ path
 
 // ---- prime field ---------------------------------------------------------------------------
 template <class P>
@@ -134,6 +139,12 @@ struct Fp {
     // CIOS Montgomery product, one 32-bit word of b per round.  MOD < 2^(32N-1) keeps the
     // running value below 2*MOD, so N+1 words suffice and the top word is 0 after each round.
     HK_HD static Fp mul(const Fp& a, const Fp& b) {
+#if defined(HK_USE_ASM_MUL)
+        // hand-scheduled product-scanning form (gen_mont_asm.py): 128 mad+addc pairs, no pair shuffles
+        if constexpr (P::ASM_ID == 1) { Fp r; HK_MONT_ASM_BN254_FR(r, a, b); return reduce_once(r); }
+        if constexpr (P::ASM_ID == 2) { Fp r; HK_MONT_ASM_BN254_FQ(r, a, b); return reduce_once(r); }
+        if constexpr (P::ASM_ID == 3) { Fp r; HK_MONT_ASM_BLS12_381_FR(r, a, b); return reduce_once(r); }
+#endif
         u32 t[N + 1];
         HK_UNROLL for (int i = 0; i <= N; i++) t[i] = 0;
         HK_UNROLL for (int i = 0; i < N; i++) {

@@ -67,12 +67,56 @@ static float timeit(K k, dim3 g, dim3 b, A... a) {
     return ms;
 }
 
+template <class F>
+__global__ void k_mul_pairs(const F* x, const F* y, F* z, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) z[t] = F::mul(x[t], y[t]);
+}
+template <class F>
+static int check_mul(const char* name) {
+    const int n = 1 << 14;
+    std::vector<F> x(n), y(n), z(n);
+    unsigned long long st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (u32)(st >> 16); };
+    auto gen = [&](F& f) {
+        for (;;) {
+            for (int i = 0; i < F::N; i++) f.v[i] = rnd();
+            f.v[F::N - 1] &= 0x3fffffffu >> (F::N == 12 ? 1 : 0);
+            bool lt = false;
+            for (int i = F::N - 1; i >= 0; i--) { if (f.v[i] < F::Params::MOD[i]) { lt = true; break; } if (f.v[i] > F::Params::MOD[i]) break; }
+            if (lt) return;
+        }
+    };
+    for (int i = 0; i < n; i++) { gen(x[i]); gen(y[i]); }
+    // edge values
+    for (int i = 0; i < F::N; i++) { x[0].v[i] = 0; x[1].v[i] = F::Params::MOD[i]; y[1].v[i] = F::Params::MOD[i]; }
+    x[1].v[0] -= 1; y[1].v[0] -= 1;
+    F *dx, *dy, *dz;
+    hipMalloc(&dx, n * sizeof(F)); hipMalloc(&dy, n * sizeof(F)); hipMalloc(&dz, n * sizeof(F));
+    hipMemcpy(dx, x.data(), n * sizeof(F), hipMemcpyHostToDevice);
+    hipMemcpy(dy, y.data(), n * sizeof(F), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL((k_mul_pairs<F>), dim3(n / 64), dim3(64), 0, 0, dx, dy, dz, n);
+    hipMemcpy(z.data(), dz, n * sizeof(F), hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < n; i++) { F w = F::mul(x[i], y[i]); if (!(w == z[i])) bad++; }
+    printf("check %s device mul vs host C++ mul: %d mismatches of %d\n", name, bad, n);
+    hipFree(dx); hipFree(dy); hipFree(dz);
+    return bad;
+}
+
 int main() {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+#if defined(HK_NO_ASM_MUL)
+    printf("build: C++ CIOS multiplication\n");
+#else
+    printf("build: inline-asm product-scanning multiplication\n");
+#endif
+    if (check_mul<Fp<Bn254FqP>>("bn254 Fq") | check_mul<Fp<Bn254FrP>>("bn254 Fr") | check_mul<Fp<Bls381FrP>>("bls Fr") |
+        check_mul<Fp<Bls381FqP>>("bls Fq")) return 2;
     printf("device %s CUs=%d clock=%d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
     const int CUs = prop.multiProcessorCount;
     void* buf; CK(hipMalloc(&buf, 512 << 20)); CK(hipMemset(buf, 1, 512 << 20));
-    for (int wpc : {4, 8, 16, 32}) {           // waves per CU
+    for (int wpc : {16}) {           // waves per CU
         dim3 g(CUs * wpc / 4), b(256);
         int iters = 20000;
         double lanes = (double)g.x * b.x;
