@@ -77,8 +77,8 @@ struct Ops {
         XYZZ<F>* res = L->alloc_n<XYZZ<F>>(1);
         Affine<F>* aff = L->alloc_n<Affine<F>>(1);
         if (!res || !aff) return HK_ERR_NOMEM;
-        HK_TRY(MsmSort<Fr>::run(L, p, (const u32*)sc_d, mont, sb));
-        HK_TRY(MsmRun<F>::run(L, p, (const Affine<F>*)b_d, (u32)n, 0, sb, rb, res, nullptr, nullptr));
+        HK_TRY(MsmSort<Fr>::run(L->stream, p, (const u32*)sc_d, mont, sb));
+        HK_TRY(MsmRun<F>::run(L->stream, p, (const Affine<F>*)b_d, (u32)n, 0, sb, rb, res, nullptr, nullptr));
         HK_TRY(MsmRun<F>::to_affine(L->stream, res, aff, 1));
         HK_HIP(hipMemcpyAsync(out, aff, sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
         HK_HIP(hipStreamSynchronize(L->stream));

@@ -34,6 +34,7 @@ LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
             (void)hipSetDevice(ctx->device);
             if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) { delete l; break; }
             for (auto& e : l->ev) (void)hipEventCreate(&e);
+            for (auto& a : l->aux) (void)hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
             memset(&l->timings, 0, sizeof(l->timings));
             ctx->lanes.push_back(l);
             lane = l;
@@ -133,6 +134,7 @@ void hk_ctx_destroy(hk_ctx* ctx) {
         if (l->arena) (void)hipFree(l->arena);
         if (l->pinned) (void)hipHostFree(l->pinned);
         for (auto& e : l->ev) (void)hipEventDestroy(e);
+        for (auto& a : l->aux) if (a) (void)hipStreamDestroy(a);
         (void)hipStreamDestroy(l->stream);
         delete l;
     }
@@ -143,7 +145,10 @@ hk_status hk_ctx_sync(hk_ctx* ctx) {
     if (!ctx) return HK_ERR_ARG;
     HK_HIP(hipSetDevice(ctx->device));
     std::unique_lock<std::mutex> lk(ctx->mu);
-    for (Lane* l : ctx->lanes) HK_HIP(hipStreamSynchronize(l->stream));
+    for (Lane* l : ctx->lanes) {
+        HK_HIP(hipStreamSynchronize(l->stream));
+        for (auto& a : l->aux) if (a) HK_HIP(hipStreamSynchronize(a));
+    }
     return HK_OK;
 }
 

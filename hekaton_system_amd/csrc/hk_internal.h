@@ -66,7 +66,8 @@ struct Lane {
     size_t arena_off = 0;
     void* pinned = nullptr;       // small host staging buffer
     size_t pinned_cap = 0;
-    hipEvent_t ev[16];
+    hipEvent_t ev[32];
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork/join side streams of hk_prove
     bool busy = false;
     hk_timings timings;
 
@@ -118,7 +119,7 @@ struct hk_ctx {
     size_t max_lanes = 8;
     hk::NttTables* ntt = nullptr;
     hk_timings last;
-    uint32_t max_lanes0 = 262144;   // level-0 accumulate lanes (one full-occupancy wave set)
+    uint32_t max_lanes0 = 131072;   // level-0 accumulate lanes: 2 waves/SIMD x 1024 SIMDs x 64
 };
 
 struct hk_pk {

@@ -27,8 +27,9 @@
 
 namespace hk {
 
-constexpr int MSM_MAX_LEVELS = 10;
-constexpr u32 MSM_LVL_L = 32;          // entries per lane on levels >= 1
+constexpr int MSM_MAX_LEVELS = 16;
+constexpr u32 MSM_LVL_L = 8;           // entries per lane on levels >= 1 (short dependent chains)
+constexpr int MSM_WSUM_THREADS = 256;
 constexpr int MSM_SORT_THREADS = 1024;
 constexpr int MSM_LDS_COUNTERS = 32768; // 128 KiB of LDS per sort workgroup
 
@@ -355,16 +356,16 @@ k_msm_bucket_reduce(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __r
 
 // one workgroup per window: LDS tree over the J lane results
 template <class F>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(MSM_WSUM_THREADS)
 k_msm_window_sum(const XYZZ<F>* __restrict__ in, MsmPlan p, XYZZ<F>* __restrict__ wsum) {
-    __shared__ XYZZ<F> sh[64];
+    __shared__ XYZZ<F> sh[MSM_WSUM_THREADS];
     u32 J = p.B / p.K;
     u32 w = blockIdx.x;
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (u32 j = threadIdx.x; j < J; j += 64) acc = ec_add_ni(acc, ld_vec(&in[(size_t)w * J + j]));
+    for (u32 j = threadIdx.x; j < J; j += MSM_WSUM_THREADS) acc = ec_add_ni(acc, ld_vec(&in[(size_t)w * J + j]));
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (u32 off = 32; off >= 1; off >>= 1) {
+    for (u32 off = MSM_WSUM_THREADS / 2; off >= 1; off >>= 1) {
         if (threadIdx.x < off) {
             XYZZ<F> a = sh[threadIdx.x], b = sh[threadIdx.x + off];
             sh[threadIdx.x] = ec_add_ni(a, b);
@@ -422,7 +423,7 @@ inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) 
     p.WP = WP;
     p.F = (p.W + WP - 1) / WP;
     p.NB = WP * p.B;
-    p.Lmin0 = 8;
+    p.Lmin0 = 32;
     u64 emax = (u64)n * p.W;
     u64 t0 = (emax + p.Lmin0 - 1) / p.Lmin0;
     if (t0 > max_lanes0) t0 = max_lanes0;
@@ -439,7 +440,7 @@ inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) 
     u32 chunk = (n + 511) / 512;
     if (chunk < 1024) chunk = 1024;
     p.chunk = chunk;
-    p.K = p.B >= 16 ? 16 : p.B;
+    p.K = p.B >= 8 ? 8 : p.B;
     for (int i = 0; i < 10; i++) p.kconst[i] = 0;
     for (u32 w = 0; w < p.W; w++) {
         u32 bit = c * w + c - 1;

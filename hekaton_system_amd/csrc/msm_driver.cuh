@@ -18,7 +18,7 @@ template <class Fr>
 struct MsmSort {
     static hk_status alloc(Lane* L, const MsmPlan& p, SortBufs* out);
     // scalars_d: n field elements on the device (canonical, or Montgomery when is_mont)
-    static hk_status run(Lane* L, const MsmPlan& p, const u32* scalars_d, int is_mont,
+    static hk_status run(hipStream_t s, const MsmPlan& p, const u32* scalars_d, int is_mont,
                          const SortBufs& sb);
 };
 
@@ -34,7 +34,7 @@ struct MsmRun {
     static hk_status alloc(Lane* L, const MsmPlan& p, Bufs* out);
     // table: F shift groups of n_bases affine points each.  result_d receives one XYZZ point.
     // ev0/ev1 (optional) bracket the bucket-accumulate launches for hk_timings.
-    static hk_status run(Lane* L, const MsmPlan& p, const Affine<F>* table, u32 n_bases, u32 idx_off,
+    static hk_status run(hipStream_t s, const MsmPlan& p, const Affine<F>* table, u32 n_bases, u32 idx_off,
                          const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
                          hipEvent_t ev0, hipEvent_t ev1);
     static hk_status build_tables(hipStream_t s, Affine<F>* table, u32 n, u32 groups, u32 shift_bits);

@@ -16,16 +16,16 @@ hk_status MsmSort<Fr>::alloc(Lane* L, const MsmPlan& p, SortBufs* out) {
 }
 
 template <class Fr>
-hk_status MsmSort<Fr>::run(Lane* L, const MsmPlan& p, const u32* scalars_d, int is_mont,
+hk_status MsmSort<Fr>::run(hipStream_t s, const MsmPlan& p, const u32* scalars_d, int is_mont,
                            const SortBufs& sb) {
     if (p.NB > (u32)MSM_LDS_COUNTERS) return HK_ERR_ARG;
-    HK_HIP(hipMemsetAsync(sb.count, 0, sizeof(u32) * p.NB, L->stream));
+    HK_HIP(hipMemsetAsync(sb.count, 0, sizeof(u32) * p.NB, s));
     u32 blocks = (p.n + p.chunk - 1) / p.chunk;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((k_msm_hist<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, L->stream,
+    hipLaunchKernelGGL((k_msm_hist<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, s,
                        scalars_d, is_mont, p, sb.count);
-    hipLaunchKernelGGL((k_msm_scan<0>), dim3(1), dim3(1024), 0, L->stream, sb.count, sb.start, sb.cursor, p.NB);
-    hipLaunchKernelGGL((k_msm_scatter<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, L->stream,
+    hipLaunchKernelGGL((k_msm_scan<0>), dim3(1), dim3(1024), 0, s, sb.count, sb.start, sb.cursor, p.NB);
+    hipLaunchKernelGGL((k_msm_scatter<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, s,
                        scalars_d, is_mont, p, sb.cursor, sb.sorted);
     HK_HIP(hipGetLastError());
     return HK_OK;
@@ -49,10 +49,9 @@ hk_status MsmRun<F>::alloc(Lane* L, const MsmPlan& p, Bufs* out) {
 }
 
 template <class F>
-hk_status MsmRun<F>::run(Lane* L, const MsmPlan& p, const Affine<F>* table, u32 n_bases, u32 idx_off,
+hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p, const Affine<F>* table, u32 n_bases, u32 idx_off,
                          const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
                          hipEvent_t ev0, hipEvent_t ev1) {
-    hipStream_t s = L->stream;
     HK_HIP(hipMemsetAsync(b.buckets, 0, sizeof(XYZZ<F>) * p.NB, s));
     if (ev0) HK_HIP(hipEventRecord(ev0, s));
     hipLaunchKernelGGL((k_msm_accum0<F>), dim3((p.T[0] + 63) / 64), dim3(64), 0, s,
@@ -66,7 +65,7 @@ hk_status MsmRun<F>::run(Lane* L, const MsmPlan& p, const Affine<F>* table, u32 
     u32 J = p.B / p.K;
     hipLaunchKernelGGL((k_msm_bucket_reduce<F>), dim3((p.WP * J + 63) / 64), dim3(64), 0, s,
                        b.buckets, p, b.red);
-    hipLaunchKernelGGL((k_msm_window_sum<F>), dim3(p.WP), dim3(64), 0, s, b.red, p, b.wsum);
+    hipLaunchKernelGGL((k_msm_window_sum<F>), dim3(p.WP), dim3(MSM_WSUM_THREADS), 0, s, b.red, p, b.wsum);
     hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, s, b.wsum, p, result_d);
     HK_HIP(hipGetLastError());
     return HK_OK;

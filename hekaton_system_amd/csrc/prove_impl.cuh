@@ -612,8 +612,8 @@ hk_status Ops<C>::commit(hk_ctx* ctx, const hk_pk* h, size_t stage, const void* 
     XYZZ<Fq>* res = L->alloc_n<XYZZ<Fq>>(1);
     Affine<Fq>* aff = L->alloc_n<Affine<Fq>>(1);
     if (!res || !aff) return HK_ERR_NOMEM;
-    HK_TRY(MsmSort<Fr>::run(L, p, (const u32*)sc, 1, sb));
-    HK_TRY(MsmRun<Fq>::run(L, p, pk->ck_tab[stage], (u32)(n + 1), 0, sb, rb, res, nullptr, nullptr));
+    HK_TRY(MsmSort<Fr>::run(s, p, (const u32*)sc, 1, sb));
+    HK_TRY(MsmRun<Fq>::run(s, p, pk->ck_tab[stage], (u32)(n + 1), 0, sb, rb, res, nullptr, nullptr));
     HK_TRY(MsmRun<Fq>::to_affine(s, res, aff, 1));
     HK_HIP(hipMemcpyAsync(out, aff, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
     if (prof) HK_HIP(hipEventRecord(L->ev[1], s));
@@ -643,7 +643,7 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     const MsmPlan &pz = pk->plan_z, &ph = pk->plan_h;
     size_t m = (size_t)1 << pk->log_m;
     size_t need = al256(sizeof(Fr) * pk->n_ext) + al256(sizeof(Fr) * n_v) + msm_sort_bytes(pz) +
-                  msm_sort_bytes(ph) + msm_run_bytes<Fq>(pz) + msm_run_bytes<Fq>(ph) +
+                  msm_sort_bytes(ph) + 3 * msm_run_bytes<Fq>(pz) + msm_run_bytes<Fq>(ph) +
                   msm_run_bytes<Fq2>(pz) + al256(3 * m * sizeof(Fr)) + 16384;
     HK_TRY(L->reserve(need));
     hipStream_t s = L->stream;
@@ -673,9 +673,11 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     SortBufs sb, sbh;
     HK_TRY(MsmSort<Fr>::alloc(L, pz, &sb));
     HK_TRY(MsmSort<Fr>::alloc(L, ph, &sbh));
-    typename MsmRun<Fq>::Bufs rb1, rbh;
+    typename MsmRun<Fq>::Bufs rbA, rbB1, rbL, rbh;
     typename MsmRun<Fq2>::Bufs rb2;
-    HK_TRY(MsmRun<Fq>::alloc(L, pz, &rb1));
+    HK_TRY(MsmRun<Fq>::alloc(L, pz, &rbA));
+    HK_TRY(MsmRun<Fq>::alloc(L, pz, &rbB1));
+    HK_TRY(MsmRun<Fq>::alloc(L, pz, &rbL));
     HK_TRY(MsmRun<Fq>::alloc(L, ph, &rbh));
     HK_TRY(MsmRun<Fq2>::alloc(L, pz, &rb2));
     XYZZ<Fq>* res1 = L->alloc_n<XYZZ<Fq>>(4);
@@ -684,44 +686,62 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     Affine<Fq2>* ob = L->alloc_n<Affine<Fq2>>(1);
     Fr* abc = L->alloc_n<Fr>(3 * m);
     if (!res1 || !res2 || !oa || !ob || !abc) return HK_ERR_NOMEM;
-    HK_TRY(MsmSort<Fr>::run(L, pz, (const u32*)zext, 1, sb));
-    HK_TRY(mark());                                                            // ev1: digits done
-    hipEvent_t ka0 = prof ? ev[10] : nullptr, ka1 = prof ? ev[11] : nullptr;
-    HK_TRY(MsmRun<Fq>::run(L, pz, pk->a_tab, pk->n_ext, 0, sb, rb1, res1 + 0, ka0, ka1));
-    HK_TRY(mark());                                                            // ev2: A
-    HK_TRY(MsmRun<Fq>::run(L, pz, pk->b1_tab, pk->n_ext, 0, sb, rb1, res1 + 1, nullptr, nullptr));
-    HK_TRY(mark());                                                            // ev3: B1
-    HK_TRY(MsmRun<Fq2>::run(L, pz, pk->b2_tab, pk->n_ext, 0, sb, rb2, res2, nullptr, nullptr));
-    HK_TRY(mark());                                                            // ev4: B2
-    HK_TRY(MsmRun<Fq>::run(L, pz, pk->l_tab, pk->l_n, pk->l_off, sb, rb1, res1 + 2, nullptr, nullptr));
-    HK_TRY(mark());                                                            // ev5: L
-    // --- quotient polynomial h (bit-reversed order, matching h_tab)
-    HK_TRY(Q::run(s, T, pk->csr[0], pk->csr[1], pk->csr[2], pk->n_inst, pk->n_c, zd, abc, pk->log_m));
-    HK_TRY(mark());                                                            // ev6: witness map
-    HK_TRY(MsmSort<Fr>::run(L, ph, (const u32*)abc, 1, sbh));
+    // Fork: the five queries are independent once their scalars exist.  Side streams let the
+    // latency-bound tails (segmented levels, bucket reduction) of one query hide under the
+    // throughput-bound accumulation of another.
+    //   main  : sort(z) -> A
+    //   aux0  : B1      aux1 : B2 (G2)      aux2 : L      aux3 : witness map -> sort(h) -> H
+    hipStream_t* ax = L->aux;
+    hipEvent_t ev_z = ev[16], ev_sorted = ev[17];
+    HK_HIP(hipEventRecord(ev_z, s));                                           // z (and ext scalars) on device
+    HK_HIP(hipStreamWaitEvent(ax[3], ev_z, 0));
+    if (prof) HK_HIP(hipEventRecord(ev[5], ax[3]));
+    HK_TRY(Q::run(ax[3], T, pk->csr[0], pk->csr[1], pk->csr[2], pk->n_inst, pk->n_c, zd, abc, pk->log_m));
+    if (prof) HK_HIP(hipEventRecord(ev[6], ax[3]));                            // witness map done
+    HK_TRY(MsmSort<Fr>::run(ax[3], ph, (const u32*)abc, 1, sbh));
     hipEvent_t kh0 = prof ? ev[12] : nullptr, kh1 = prof ? ev[13] : nullptr;
-    HK_TRY(MsmRun<Fq>::run(L, ph, pk->h_tab, (u32)m, 0, sbh, rbh, res1 + 3, kh0, kh1));
-    HK_TRY(mark());                                                            // ev7: H
+    HK_TRY(MsmRun<Fq>::run(ax[3], ph, pk->h_tab, (u32)m, 0, sbh, rbh, res1 + 3, kh0, kh1));
+    HK_HIP(hipEventRecord(ev[7], ax[3]));                                      // H done
+    HK_TRY(MsmSort<Fr>::run(s, pz, (const u32*)zext, 1, sb));
+    HK_HIP(hipEventRecord(ev_sorted, s));
+    HK_TRY(mark());                                                            // ev1: digits done
+    for (int k = 0; k < 3; k++) HK_HIP(hipStreamWaitEvent(ax[k], ev_sorted, 0));
+    HK_TRY(MsmRun<Fq2>::run(ax[1], pz, pk->b2_tab, pk->n_ext, 0, sb, rb2, res2, nullptr, nullptr));
+    HK_HIP(hipEventRecord(ev[4], ax[1]));                                      // B2 done
+    HK_TRY(MsmRun<Fq>::run(ax[0], pz, pk->b1_tab, pk->n_ext, 0, sb, rbB1, res1 + 1, nullptr, nullptr));
+    HK_HIP(hipEventRecord(ev[3], ax[0]));                                      // B1 done
+    HK_TRY(MsmRun<Fq>::run(ax[2], pz, pk->l_tab, pk->l_n, pk->l_off, sb, rbL, res1 + 2, nullptr, nullptr));
+    HK_HIP(hipEventRecord(ev[18], ax[2]));                                     // L done
+    HK_TRY(MsmRun<Fq>::run(s, pz, pk->a_tab, pk->n_ext, 0, sb, rbA, res1 + 0, nullptr, nullptr));
+    HK_TRY(mark());                                                            // ev2: A done
+    // Join
+    HK_HIP(hipStreamWaitEvent(s, ev[3], 0));
+    HK_HIP(hipStreamWaitEvent(s, ev[4], 0));
+    HK_HIP(hipStreamWaitEvent(s, ev[18], 0));
+    HK_HIP(hipStreamWaitEvent(s, ev[7], 0));
+    if (prof) HK_HIP(hipEventRecord(ev[19], s));                               // all queries done
     hipLaunchKernelGGL((k_finish<Fr, Fq, Fq2>), dim3(3), dim3(64), 0, s, res1, res2, pk->consts_g1,
                        pk->consts_g2, small, oa, ob, oa + 1);
     HK_HIP(hipGetLastError());
     HK_HIP(hipMemcpyAsync(out_a, oa, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
     HK_HIP(hipMemcpyAsync(out_b, ob, sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, s));
     HK_HIP(hipMemcpyAsync(out_c, oa + 1, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
-    HK_TRY(mark());                                                            // ev8: finish
+    if (prof) HK_HIP(hipEventRecord(ev[8], s));
     HK_HIP(hipStreamSynchronize(s));
     if (prof) {
         hk_timings& t = L->timings;
         memset(&t, 0, sizeof(t));
+        // the five queries run concurrently on side streams: each figure is the elapsed time on the
+        // query's own stream since its fork point (they overlap, they do not add up to total_ms)
         t.total_ms = ev_ms(ev[0], ev[8]);
         t.digits_ms = ev_ms(ev[0], ev[1]);
         t.msm_a_ms = ev_ms(ev[1], ev[2]);
-        t.msm_b_g1_ms = ev_ms(ev[2], ev[3]);
-        t.msm_b_g2_ms = ev_ms(ev[3], ev[4]);
-        t.msm_l_ms = ev_ms(ev[4], ev[5]);
+        t.msm_b_g1_ms = ev_ms(ev[1], ev[3]);
+        t.msm_b_g2_ms = ev_ms(ev[1], ev[4]);
+        t.msm_l_ms = ev_ms(ev[1], ev[18]);
         t.witness_map_ms = ev_ms(ev[5], ev[6]);
         t.msm_h_ms = ev_ms(ev[6], ev[7]);
-        t.finish_ms = ev_ms(ev[7], ev[8]);
+        t.finish_ms = ev_ms(ev[19], ev[8]);
         t.accum_kernel_ms = ev_ms(ev[12], ev[13]);          // H-query bucket accumulation (dominant kernel)
         t.accum_kernel_launches = 1;
     }

@@ -1,0 +1,138 @@
+"""Host-side mirror of the reference's worker protocol for the hot path (one process per GPU).
+
+    Stage0Request/Response, Stage1Request/Response     distributed-prover/src/worker.rs:20-71,
+                                                       coordinator.rs:195-199,520-532
+    process_stage0_request_get_cb                      distributed-prover/src/worker.rs:91-146
+    process_stage1_request_with_cb                     distributed-prover/src/worker.rs:150-195
+    WorkerState.{stage_0,stage_1}                      mpi-snark/src/worker.rs:25-87
+    shard / gather                                     mpi-snark/src/bin/node.rs:471-472,490-506,523-533
+
+The reference scatters requests and gathers responses with MPI (rank 0 = coordinator).  Here every
+rank is a worker on its own GPU; subcircuits are sharded contiguously and the fixed-size response
+records are all-gathered with torch.distributed (RCCL on GPUs, gloo in the CPU tests).  There is no
+collective on the data path: a response is 104 B (stage 0) / 264 B (stage 1) for BN254.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .cp_groth16 import CommitmentBuilder, Proof, SeededRng
+
+
+@dataclass
+class Stage0Request:                 # coordinator.rs:195-199 (subtraces carried as witness ints)
+    subcircuit_idx: int
+    time_ordered_subtrace: list = field(default_factory=list)
+    addr_ordered_subtrace: list = field(default_factory=list)
+
+
+@dataclass
+class Stage0Response:                # worker.rs:20-25
+    subcircuit_idx: int
+    com: np.ndarray                  # packed G1
+    com_seed: bytes                  # 32 bytes
+
+    def to_record(self):
+        return np.concatenate([np.frombuffer(int(self.subcircuit_idx).to_bytes(8, "little"), np.uint8),
+                               np.asarray(self.com, np.uint8), np.frombuffer(self.com_seed, np.uint8)])
+
+    @classmethod
+    def from_record(cls, rec, g1_bytes):
+        rec = np.asarray(rec, np.uint8)
+        return cls(int.from_bytes(rec[:8].tobytes(), "little"), rec[8:8 + g1_bytes].copy(),
+                   rec[8 + g1_bytes:8 + g1_bytes + 32].tobytes())
+
+
+@dataclass
+class Stage1Request:                 # coordinator.rs:520-532 (only what the hot path consumes)
+    subcircuit_idx: int
+    witness_seed: int = 0            # selects the synthetic subcircuit's stage-1 assignment
+
+
+@dataclass
+class Stage1Response:                # worker.rs:49-52
+    subcircuit_idx: int
+    proof: Proof
+
+    def to_record(self):
+        p = self.proof
+        parts = [np.frombuffer(int(self.subcircuit_idx).to_bytes(8, "little"), np.uint8),
+                 np.asarray(p.a, np.uint8), np.asarray(p.b, np.uint8), np.asarray(p.c, np.uint8)]
+        parts += [np.asarray(d, np.uint8) for d in p.ds]
+        return np.concatenate(parts)
+
+    @classmethod
+    def from_record(cls, rec, g1_bytes, g2_bytes):
+        rec = np.asarray(rec, np.uint8)
+        o = 8
+        a = rec[o:o + g1_bytes].copy(); o += g1_bytes
+        b = rec[o:o + g2_bytes].copy(); o += g2_bytes
+        c = rec[o:o + g1_bytes].copy(); o += g1_bytes
+        ds = [rec[k:k + g1_bytes].copy() for k in range(o, len(rec), g1_bytes)]
+        return cls(int.from_bytes(rec[:8].tobytes(), "little"), Proof(a, b, c, ds))
+
+
+def process_stage0_request_get_cb(rng, pk, req, circuit):
+    """worker.rs:91-146: draw com_seed from `rng`, commit stage 0 with ChaCha(com_seed)'s first draw as
+    the randomness, return (response, commitment builder)."""
+    circuit.subcircuit_idx = req.subcircuit_idx
+    com_seed = rng.gen_seed()                                   # worker.rs:129
+    subcircuit_rng = SeededRng(com_seed)
+    cb = CommitmentBuilder.new(circuit, pk)
+    com, _ = cb.commit(subcircuit_rng)                          # worker.rs:134-137
+    return Stage0Response(req.subcircuit_idx, com, com_seed), cb
+
+
+def process_stage1_request_with_cb(rng, cb, com, rand, stage1_req):
+    """worker.rs:150-195."""
+    assert getattr(cb.circuit, "subcircuit_idx", stage1_req.subcircuit_idx) == stage1_req.subcircuit_idx
+    proof = cb.prove([com], [rand], rng)                        # worker.rs:189
+    return Stage1Response(stage1_req.subcircuit_idx, proof)
+
+
+class WorkerState:
+    """mpi-snark/src/worker.rs:25-87: keeps the commitment builder between the two rounds and
+    re-derives the commitment randomness from `com_seed` (worker.rs:63-66)."""
+
+    def __init__(self, num_subcircuits, pk_for_idx, circuit_for_idx, r_mod):
+        self.num_subcircuits = num_subcircuits
+        self.pk_for_idx = pk_for_idx
+        self.circuit_for_idx = circuit_for_idx
+        self.r_mod = r_mod
+        self.cb = None
+        self.com = None
+        self.com_rand = None
+
+    def stage_0(self, rng, stage0_req):
+        pk = self.pk_for_idx(stage0_req.subcircuit_idx)
+        resp, cb = process_stage0_request_get_cb(rng, pk, stage0_req, self.circuit_for_idx(stage0_req.subcircuit_idx))
+        self.cb, self.com = cb, resp.com
+        self.com_rand = SeededRng(resp.com_seed).fr(self.r_mod)
+        return resp
+
+    def stage_1(self, rng, stage1_req):
+        return process_stage1_request_with_cb(rng, self.cb, self.com, self.com_rand, stage1_req)
+
+
+# ---- sharding and gathering (the only multi-GPU logic this path has) ---------------------------------
+
+def shard_range(num_subcircuits, num_workers, worker):
+    """node.rs:471-472,490-493: contiguous chunks of num_subcircuits / num_workers (must divide)."""
+    if num_subcircuits % num_workers != 0:
+        raise AssertionError("num_subcircuits % num_workers == 0")     # node.rs:472
+    per = num_subcircuits // num_workers
+    return range(worker * per, (worker + 1) * per)
+
+
+def gather_records(local_records, world_size, device="cpu"):
+    """All ranks contribute the same number of equal-sized uint8 records; every rank gets all of them in
+    subcircuit order (node.rs:500-506,526-533 gather on the root; fixed-size records instead of the
+    reference's length-prefixed `Vec<Response>` framing)."""
+    import torch
+    import torch.distributed as dist
+    local = torch.from_numpy(np.stack(local_records)).to(device)
+    if world_size == 1:
+        return local.cpu().numpy()
+    out = [torch.empty_like(local) for _ in range(world_size)]
+    dist.all_gather(out, local)
+    return torch.cat(out, dim=0).cpu().numpy()
