@@ -40,7 +40,7 @@ def parse():
                     help="workload (hekaton_system_amd/workload.py CONFIGS); default = BASELINE configs[1]")
     ap.add_argument("--curve", default="bn254", help="bn254 is what the reference instantiates (SURVEY F1)")
     ap.add_argument("--subcircuits", type=int, default=8, help="subcircuits per GPU per step")
-    ap.add_argument("--threads", type=int, default=4, help="host threads (= GPU lanes) proving concurrently")
+    ap.add_argument("--threads", type=int, default=8, help="host threads (= GPU lanes) proving concurrently")
     ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

@@ -8,6 +8,10 @@ import os
 
 import numpy as np
 
+# hk_prove forks five side streams per lane; let the runtime map them onto more hardware queues than
+# its default of 4 (must be set before the HIP runtime initialises; harmless if the user set it)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhekaton.so")
 

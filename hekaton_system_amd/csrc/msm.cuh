@@ -231,12 +231,17 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
     return lo;
 }
 
+// occupancy the accumulate kernel is compiled for (waves per SIMD): the 8-limb G1 kernel fits 168
+// VGPRs without spilling (3 waves); wider coordinates keep the compiler's default
+template <class F> struct AccumOcc { static constexpr int waves = 1; };
+template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 3 : 2; };
+
 // ---- level 0: equal slices of the sorted entry list, mixed adds into registers ---------------------
 // The sorted list was built for `n_entries` scalars per group; this base table has `n_bases` bases per
 // group and its base j corresponds to scalar j + idx_off (the L-query is a suffix of the assignment:
 // cp-groth16/src/prover.rs:111-117 vs :78-82).
 template <class F>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, AccumOcc<F>::waves)
 k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
              const u32* __restrict__ sorted, const u32* __restrict__ start, MsmPlan p,
              XYZZ<F>* __restrict__ buckets, u32* __restrict__ pkeys, XYZZ<F>* __restrict__ ppts) {

@@ -55,6 +55,25 @@ __global__ void k_madd(const Affine<F>* in, XYZZ<F>* out, int iters, int npts) {
     out[t] = acc;
 }
 
+// the real access pattern of k_msm_accum0: entry id from a list, then a dependent 64-B gather
+template <class F, int WAVES>
+__global__ void __launch_bounds__(64, WAVES) k_madd_idx(const Affine<F>* tab, const u32* idx, XYZZ<F>* out, int iters, int prefetch) {
+    size_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32* my = idx + t * iters;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (!prefetch) {
+        for (int i = 0; i < iters; i++) acc = ec_madd(acc, tab[my[i]]);
+    } else {
+        Affine<F> nxt = tab[my[0]];
+        for (int i = 0; i < iters; i++) {
+            Affine<F> cur = nxt;
+            if (i + 1 < iters) nxt = tab[my[i + 1]];
+            acc = ec_madd(acc, cur);
+        }
+    }
+    out[t] = acc;
+}
+
 template <class K, class... A>
 static float timeit(K k, dim3 g, dim3 b, A... a) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -153,6 +172,29 @@ int main() {
         double lanes = (double)g.x * b.x;
         float t = timeit(k_madd<Fq>, g, b, (const Affine<Fq>*)buf, (XYZZ<Fq>*)((char*)buf + (256 << 20)), iters, 1 << 20);
         printf("waves/CU=%2d  G1-254 madd (random 64B gathers): %8.2f Gadd/s chip\n", wpc, lanes * iters / t / 1e6);
+    }
+    {
+        // table-size sweep with the accumulate kernel's access pattern (index list -> gather)
+        typedef Fp<Bn254FqP> Fq;
+        size_t maxpts = (size_t)1 << 25;                 // 2 GiB of affine G1 points
+        Affine<Fq>* tab; u32* idx; XYZZ<Fq>* outp;
+        int iters = 128;
+        size_t lanes = (size_t)CUs * 12 * 64;
+        CK(hipMalloc(&tab, maxpts * sizeof(Affine<Fq>))); CK(hipMemset(tab, 1, maxpts * sizeof(Affine<Fq>)));
+        CK(hipMalloc(&idx, lanes * iters * 4)); CK(hipMalloc(&outp, lanes * sizeof(XYZZ<Fq>)));
+        std::vector<u32> h(lanes * iters);
+        for (int lg : {20, 23, 25}) {
+            unsigned long long st = 88172645463325252ull;
+            for (auto& v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = (u32)(st >> 20) & ((1u << lg) - 1); }
+            CK(hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            for (int pf : {0, 1}) {
+                float t2 = timeit(k_madd_idx<Fq, 2>, dim3(lanes / 64), dim3(64), tab, idx, outp, iters, pf);
+                float t3 = timeit(k_madd_idx<Fq, 3>, dim3(lanes / 64), dim3(64), tab, idx, outp, iters, pf);
+                printf("G1 madd via index list, table 2^%d pts (%4zu MiB), prefetch=%d: occ2 %6.2f Gadd/s  occ3 %6.2f Gadd/s\n",
+                       lg, ((size_t)64 << lg) >> 20, pf, lanes * (double)iters / t2 / 1e6, lanes * (double)iters / t3 / 1e6);
+            }
+        }
+        hipFree(tab); hipFree(idx); hipFree(outp);
     }
     for (int wpc : {4, 8}) {
         dim3 g(CUs * wpc), b(64);
