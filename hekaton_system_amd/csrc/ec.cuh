@@ -72,10 +72,16 @@ HK_HD XYZZ<F> ec_dbl(const XYZZ<F>& p) {
     return r;
 }
 
+// NOTE: keep the P == Q corner of ec_add out of line.  With it inlined, the (already out-of-line)
+// ec_add_ni of the 12-limb BLS12-381 fields faulted on the GPU ("memory access fault" in the private
+// aperture, k_msm_bucket_reduce) although the same source is fine for 8-limb fields — see DESIGN.md.
 template <class F>
 HK_RARE XYZZ<F> ec_dbl_rare(const XYZZ<F>& p) { return ec_dbl(p); }
 
-// acc + affine q  ("madd-2008-s"), all exceptional cases handled
+// acc + affine q  ("madd-2008-s"), all exceptional cases handled.  Everything is inlined, including
+// the P == Q corner: an out-of-line call there takes the addresses of `a`/`q`, which forces hipcc to
+// keep copies of them in scratch memory on EVERY iteration of the accumulate loop (rocprofv3 showed
+// 6.3 GB of WRITE_SIZE per 2^21-point MSM from it).
 template <class F>
 HK_HD XYZZ<F> ec_madd(const XYZZ<F>& a, const Affine<F>& q) {
     if (q.is_inf()) return a;
@@ -84,14 +90,28 @@ HK_HD XYZZ<F> ec_madd(const XYZZ<F>& a, const Affine<F>& q) {
     F s2 = F::mul(q.y, a.zzz);
     F p = F::sub(u2, a.x);
     F r = F::sub(s2, a.y);
+    XYZZ<F> o;
     if (p.is_zero()) {
-        if (r.is_zero()) return ec_dbl_affine(q);
-        return XYZZ<F>::inf();
+        if (!r.is_zero()) return XYZZ<F>::inf();
+        // 12-limb coordinate fields keep the out-of-line form: their kernels are at the edge of what
+        // hipcc/gfx950 handles (see the note at ec_dbl_rare and DESIGN.md), and are not the benched path
+        if constexpr (F::Params::N > 8) return ec_dbl_affine(q);
+        // doubling of the affine point ("mdbl-2008-s-1", a = 0)
+        F u = F::dbl(q.y);
+        F v = F::sqr(u);
+        F w = F::mul(u, v);
+        F s = F::mul(q.x, v);
+        F xx = F::sqr(q.x);
+        F m = F::add(F::dbl(xx), xx);
+        o.x = F::sub(F::sqr(m), F::dbl(s));
+        o.y = F::sub(F::mul(m, F::sub(s, o.x)), F::mul(w, q.y));
+        o.zz = v;
+        o.zzz = w;
+        return o;
     }
     F pp = F::sqr(p);
     F ppp = F::mul(p, pp);
     F qq = F::mul(a.x, pp);
-    XYZZ<F> o;
     o.x = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
     o.y = F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(a.y, ppp));
     o.zz = F::mul(a.zz, pp);

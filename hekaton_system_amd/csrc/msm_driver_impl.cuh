@@ -5,6 +5,17 @@
 
 namespace hk {
 
+// HK_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (locates a faulting kernel)
+static inline bool hk_dbg_sync() { static const bool on = getenv("HK_DEBUG_SYNC") != nullptr; return on; }
+#define HK_DBG(stream, name)                                                              \
+    do {                                                                                  \
+        if (hk_dbg_sync()) {                                                              \
+            fprintf(stderr, "[hk] launched %s\n", name); fflush(stderr);                  \
+            hipError_t _e = hipStreamSynchronize(stream);                                 \
+            fprintf(stderr, "[hk] finished %s: %s\n", name, hipGetErrorName(_e)); fflush(stderr); \
+        }                                                                                 \
+    } while (0)
+
 template <class Fr>
 hk_status MsmSort<Fr>::alloc(Lane* L, const MsmPlan& p, SortBufs* out) {
     out->count = L->alloc_n<u32>(p.NB);
@@ -24,9 +35,12 @@ hk_status MsmSort<Fr>::run(hipStream_t s, const MsmPlan& p, const u32* scalars_d
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL((k_msm_hist<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, s,
                        scalars_d, is_mont, p, sb.count);
+    HK_DBG(s, "k_msm_hist");
     hipLaunchKernelGGL((k_msm_scan<0>), dim3(1), dim3(1024), 0, s, sb.count, sb.start, sb.cursor, p.NB);
+    HK_DBG(s, "k_msm_scan");
     hipLaunchKernelGGL((k_msm_scatter<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, s,
                        scalars_d, is_mont, p, sb.cursor, sb.sorted);
+    HK_DBG(s, "k_msm_scatter");
     HK_HIP(hipGetLastError());
     return HK_OK;
 }
@@ -56,17 +70,22 @@ hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p, const Affine<F>* table
     if (ev0) HK_HIP(hipEventRecord(ev0, s));
     hipLaunchKernelGGL((k_msm_accum0<F>), dim3((p.T[0] + 63) / 64), dim3(64), 0, s,
                        table, n_bases, idx_off, sb.sorted, sb.start, p, b.buckets, b.pkeys[0], b.ppts[0]);
+    HK_DBG(s, "k_msm_accum0");
     if (ev1) HK_HIP(hipEventRecord(ev1, s));
     for (u32 k = 1; k < p.n_levels; k++) {
         int in = (k - 1) & 1, out = k & 1;
         hipLaunchKernelGGL((k_msm_accum_lvl<F>), dim3((p.T[k] + 63) / 64), dim3(64), 0, s,
                            (int)k, b.pkeys[in], b.ppts[in], sb.start, p, b.buckets, b.pkeys[out], b.ppts[out]);
+        HK_DBG(s, "k_msm_accum_lvl");
     }
     u32 J = p.B / p.K;
     hipLaunchKernelGGL((k_msm_bucket_reduce<F>), dim3((p.WP * J + 63) / 64), dim3(64), 0, s,
                        b.buckets, p, b.red);
+    HK_DBG(s, "k_msm_bucket_reduce");
     hipLaunchKernelGGL((k_msm_window_sum<F>), dim3(p.WP), dim3(MSM_WSUM_THREADS), 0, s, b.red, p, b.wsum);
+    HK_DBG(s, "k_msm_window_sum");
     hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, s, b.wsum, p, result_d);
+    HK_DBG(s, "k_msm_final");
     HK_HIP(hipGetLastError());
     return HK_OK;
 }
@@ -83,6 +102,7 @@ hk_status MsmRun<F>::build_tables(hipStream_t s, Affine<F>* table, u32 n, u32 gr
 template <class F>
 hk_status MsmRun<F>::to_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, u32 n) {
     hipLaunchKernelGGL((k_to_affine<F>), dim3((n + 63) / 64), dim3(64), 0, s, in, out, n);
+    HK_DBG(s, "k_to_affine");
     HK_HIP(hipGetLastError());
     return HK_OK;
 }

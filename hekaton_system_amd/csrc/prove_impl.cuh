@@ -691,7 +691,10 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     // throughput-bound accumulation of another.
     //   main  : sort(z) -> A
     //   aux0  : B1      aux1 : B2 (G2)      aux2 : L      aux3 : witness map -> sort(h) -> H
-    hipStream_t* ax = L->aux;
+    hipStream_t axs[4] = {L->aux[0], L->aux[1], L->aux[2], L->aux[3]};
+    static const bool serial = getenv("HK_SERIAL_STREAMS") != nullptr;   // profiling aid: clean per-kernel times
+    if (serial) for (auto& a : axs) a = s;
+    hipStream_t* ax = axs;
     hipEvent_t ev_z = ev[16], ev_sorted = ev[17];
     HK_HIP(hipEventRecord(ev_z, s));                                           // z (and ext scalars) on device
     HK_HIP(hipStreamWaitEvent(ax[3], ev_z, 0));
