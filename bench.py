@@ -167,6 +167,16 @@ def main():
         avg_ms = float(np.mean(accum_ms)) if accum_ms else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         nprov = max(1, len(accum_ms))
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (profiles/, collected offline with
+        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this command; cannot be read live)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_accum0.json")) as f:
+                pmc = json.load(f)
+            if args.config == "big-merkle-64x32" and args.curve == "bn254":
+                traffic = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
+        except Exception:       # noqa: BLE001
+            pass
         out = {
             "metric": "subcircuit Groth16 proofs/sec (whole node), big-merkle",
             "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
@@ -179,7 +189,7 @@ def main():
                        "host_threads_per_gpu": args.threads, "sharding": "subcircuits/%d per rank" % world},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accum0<Fq> (H-query bucket accumulation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms},
             "phase_ms_per_proof": {k: v / nprov for k, v in phase.items() if k.endswith("_ms")},
         }

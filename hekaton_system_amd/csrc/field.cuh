@@ -203,19 +203,25 @@ struct Fp2 {
     HK_HD static Fp2 sub(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = B::sub(a.c0, b.c0); r.c1 = B::sub(a.c1, b.c1); return r; }
     HK_HD static Fp2 dbl(const Fp2& a) { return add(a, a); }
     HK_HD static Fp2 neg(const Fp2& a) { Fp2 r; r.c0 = B::neg(a.c0); r.c1 = B::neg(a.c1); return r; }
+    // base-field product used by the extension: inline (asm block) for 8-limb fields, an out-of-line
+    // call with register arguments for 12-limb fields (keeps BLS12-381 code size and scratch small)
+    HK_HD static B bmul(const B& x, const B& y) {
+        if constexpr (P::N <= 8) return B::mul(x, y);
+        else return B::mul_call(x, y);
+    }
     HK_HD static Fp2 mul(const Fp2& a, const Fp2& b) {       // Karatsuba, 3 base muls
-        B v0 = B::mul_call(a.c0, b.c0);
-        B v1 = B::mul_call(a.c1, b.c1);
-        B s = B::mul_call(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        B v0 = bmul(a.c0, b.c0);
+        B v1 = bmul(a.c1, b.c1);
+        B s = bmul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
         Fp2 r;
         r.c0 = B::sub(v0, v1);
         r.c1 = B::sub(B::sub(s, v0), v1);
         return r;
     }
     HK_HD static Fp2 sqr(const Fp2& a) {                     // (a0+a1)(a0-a1), 2 a0 a1
-        B t = B::mul_call(a.c0, a.c1);
+        B t = bmul(a.c0, a.c1);
         Fp2 r;
-        r.c0 = B::mul_call(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
+        r.c0 = bmul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
         r.c1 = B::dbl(t);
         return r;
     }

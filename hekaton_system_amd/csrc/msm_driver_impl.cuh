@@ -1,5 +1,6 @@
 // msm_driver_impl.cuh — definitions for msm_driver.cuh (see there).
 #pragma once
+#include <hip/hip_ext.h>
 #include "msm_driver.cuh"
 #include "fixed_base.cuh"
 
@@ -67,11 +68,15 @@ hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p, const Affine<F>* table
                          const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
                          hipEvent_t ev0, hipEvent_t ev1) {
     HK_HIP(hipMemsetAsync(b.buckets, 0, sizeof(XYZZ<F>) * p.NB, s));
-    if (ev0) HK_HIP(hipEventRecord(ev0, s));
-    hipLaunchKernelGGL((k_msm_accum0<F>), dim3((p.T[0] + 63) / 64), dim3(64), 0, s,
-                       table, n_bases, idx_off, sb.sorted, sb.start, p, b.buckets, b.pkeys[0], b.ppts[0]);
+    // with profiling on, ev0/ev1 take the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), so
+    // the figure agrees with rocprofv3's kernel trace even when other lanes share the hardware queues
+    if (ev0 && ev1)
+        hipExtLaunchKernelGGL((k_msm_accum0<F>), dim3((p.T[0] + 63) / 64), dim3(64), 0, s, ev0, ev1, 0,
+                              table, n_bases, idx_off, sb.sorted, sb.start, p, b.buckets, b.pkeys[0], b.ppts[0]);
+    else
+        hipLaunchKernelGGL((k_msm_accum0<F>), dim3((p.T[0] + 63) / 64), dim3(64), 0, s,
+                           table, n_bases, idx_off, sb.sorted, sb.start, p, b.buckets, b.pkeys[0], b.ppts[0]);
     HK_DBG(s, "k_msm_accum0");
-    if (ev1) HK_HIP(hipEventRecord(ev1, s));
     for (u32 k = 1; k < p.n_levels; k++) {
         int in = (k - 1) & 1, out = k & 1;
         hipLaunchKernelGGL((k_msm_accum_lvl<F>), dim3((p.T[k] + 63) / 64), dim3(64), 0, s,

@@ -74,6 +74,14 @@ __global__ void __launch_bounds__(64, WAVES) k_madd_idx(const Affine<F>* tab, co
     out[t] = acc;
 }
 
+template <class F, int WAVES>
+__global__ void __launch_bounds__(64, WAVES) k_madd_occ(const Affine<F>* in, XYZZ<F>* out, int iters, int npts) {
+    size_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::from_affine(in[t % npts]);
+    for (int i = 1; i <= iters; i++) acc = ec_madd(acc, in[(t + i * 7919u) % npts]);
+    out[t] = acc;
+}
+
 template <class K, class... A>
 static float timeit(K k, dim3 g, dim3 b, A... a) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -195,6 +203,17 @@ int main() {
             }
         }
         hipFree(tab); hipFree(idx); hipFree(outp);
+    }
+    {
+        typedef Fp2<Bn254FqP> F2;
+        int iters = 100;
+        for (int wpc : {4, 8, 12}) {
+            dim3 g(CUs * wpc), b(64);
+            double lanes = (double)g.x * b.x;
+            float t1 = timeit(k_madd_occ<F2, 1>, g, b, (const Affine<F2>*)buf, (XYZZ<F2>*)((char*)buf + (256 << 20)), iters, 1 << 19);
+            float t2 = timeit(k_madd_occ<F2, 2>, g, b, (const Affine<F2>*)buf, (XYZZ<F2>*)((char*)buf + (256 << 20)), iters, 1 << 19);
+            printf("waves/CU=%2d  G2-254 madd  launch_bounds occ1: %6.2f Gadd/s   occ2: %6.2f Gadd/s\n", wpc, lanes * iters / t1 / 1e6, lanes * iters / t2 / 1e6);
+        }
     }
     for (int wpc : {4, 8}) {
         dim3 g(CUs * wpc), b(64);
