@@ -17,7 +17,7 @@ namespace hk {
 
 constexpr int NTT_TILE_LOG_ROWS = 8;     // stages per pass
 constexpr int NTT_TILE_LOG_COLS = 3;     // 8 contiguous elements = 256 B per row
-constexpr int NTT_THREADS = 256;
+constexpr int NTT_THREADS = 256;         // 512 measured no faster: the passes are bound by field-multiply issue, not latency
 constexpr int POW_TABLE_BITS = 10;       // g^j = T0[j & 1023] * T1[(j >> 10) & 1023] * T2[j >> 20]
 
 #if defined(__HIPCC__)
@@ -53,10 +53,13 @@ __global__ void k_pow_table(Fr* __restrict__ tw, const Fr* __restrict__ sq, u32 
 //   DIF (dit == 0): stages run from high to low, butterfly (u, v) -> (u + v, (u - v) * w)
 //   DIT (dit == 1): stages run from low to high, butterfly (u, v) -> (u + v*w, u - v*w)
 // tw: table of w_M^i, i < M/2, M = 2^log_table.  Batched over blockIdx.y (vectors `stride_vec` apart).
+// Optional fused epilogue (post != 0): every element is multiplied by `scale` and, when post == 2, also by
+// g^bitrev(index) from the 3x1024 power tables `pw` before it is stored — the "/m and coset shift"
+// step that follows a DIF chain in the witness map, so it costs no extra HBM round trip.
 template <class Fr>
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ tw, u32 logn, u32 log_table,
-           u32 lo, u32 nst, int dit) {
+           u32 lo, u32 nst, int dit, int post, Fr scale, const Fr* __restrict__ pw) {
     extern __shared__ uint4 lds_raw[];
     Fr* lds = reinterpret_cast<Fr*>(lds_raw);
     Fr* vec = data + (size_t)blockIdx.y * stride_vec;
@@ -87,7 +90,7 @@ k_ntt_pass(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ tw, 
             u32 i0 = (r0 << cols_bits) | c, i1 = (r1 << cols_bits) | c;
             size_t g0 = base | ((size_t)r0 << lo) | c;           // global index of the upper element
             u32 j = (u32)(g0 & (((size_t)1 << s) - 1));
-            Fr w = fr_load(&tw[(size_t)j << (log_table - s - 1)]);
+            Fr w = fr_load(&tw[(size_t)j << (log_table - s - 1)]);   // issued first: longest latency
             Fr u = lds[i0], v = lds[i1];
             if (dit) {
                 v = Fr::mul(v, w);
@@ -102,7 +105,19 @@ k_ntt_pass(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ tw, 
     }
     for (u32 e = threadIdx.x; e < tile_elems; e += NTT_THREADS) {
         u32 r = e >> cols_bits, c = e & (cols - 1);
-        fr_store(&vec[base | ((size_t)r << lo) | c], lds[e]);
+        size_t gi = base | ((size_t)r << lo) | c;
+        Fr x = lds[e];
+        if (post) {
+            x = Fr::mul(x, scale);
+            if (post == 2) {
+                u32 j = logn ? (__brev((u32)gi) >> (32 - logn)) : 0u;
+                Fr g = fr_load(&pw[j & 1023]);
+                if (logn > 10) g = Fr::mul(g, fr_load(&pw[1024 + ((j >> 10) & 1023)]));
+                if (logn > 20) g = Fr::mul(g, fr_load(&pw[2048 + (j >> 20)]));
+                x = Fr::mul(x, g);
+            }
+        }
+        fr_store(&vec[gi], x);
     }
 }
 

@@ -124,9 +124,11 @@ struct NttHost {
         return fp_inv(Fr::sub(g, Fr::one()));
     }
 
-    // all butterfly stages of a size-2^logn transform, `batch` vectors `stride` elements apart
+    // all butterfly stages of a size-2^logn transform, `batch` vectors `stride` elements apart.
+    // post/scale/pw: optional fused epilogue of the LAST pass (see k_ntt_pass).
     static hk_status passes(hipStream_t s, Fr* data, size_t stride, u32 batch, u32 logn, const Fr* tw,
-                            u32 log_table, int dit) {
+                            u32 log_table, int dit, int post = 0, const Fr* scale = nullptr,
+                            const Fr* pw = nullptr) {
         if (logn == 0) return HK_OK;
         // bottom pass takes up to 11 stages (tile = 2^11 contiguous elements), the rest split evenly
         u32 bottom = logn < 11 ? logn : 11;
@@ -141,14 +143,17 @@ struct NttHost {
             ps[np++] = {lo, nst};
             lo += nst;
         }
+        Fr one = Fr::one();
         for (int k = 0; k < np; k++) {
             const P& p = dit ? ps[k] : ps[np - 1 - k];
             u32 cols_bits = p.lo < (u32)NTT_TILE_LOG_COLS ? p.lo : (u32)NTT_TILE_LOG_COLS;
             u32 tile_log = p.nst + cols_bits;
             u32 tiles = 1u << (logn - tile_log);
             size_t lds = sizeof(Fr) << tile_log;
+            bool last = k == np - 1;
             hipLaunchKernelGGL((k_ntt_pass<Fr>), dim3(tiles, batch), dim3(NTT_THREADS), lds, s, data, stride,
-                               tw, logn, log_table, p.lo, p.nst, dit);
+                               tw, logn, log_table, p.lo, p.nst, dit, last ? post : 0,
+                               (last && post) ? *scale : one, pw);
         }
         HK_HIP(hipGetLastError());
         return HK_OK;
@@ -195,8 +200,9 @@ hk_status Ops<C>::ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int 
         HK_TRY(N::bitrev(s, d, log_m));
     } else {
         // iFFT: DIF with w^-1, scale by 1/m (and g^-j for the coset form), un-permute
-        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0));
-        HK_TRY(N::scale(s, d, n, 1, log_m, (const Fr*)T->pw_ginv, N::size_inv(log_m), 1, coset));
+        Fr minv = N::size_inv(log_m);
+        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0, coset ? 2 : 1, &minv,
+                         (const Fr*)T->pw_ginv));
         HK_TRY(N::bitrev(s, d, log_m));
     }
     if (!dev) HK_HIP(hipMemcpyAsync(data, d, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
@@ -233,14 +239,14 @@ struct QapHost {
         hipLaunchKernelGGL((k_copy_inputs<Fr>), dim3((u32)((n_inst + 255) / 256)), dim3(256), 0, s, abc, z,
                            (u32)n_c, (u32)n_inst);
         Fr minv = N::size_inv(log_m);
-        HK_TRY(N::passes(s, abc, m, 3, log_m, (const Fr*)T->tw_inv, T->log_table, 0));       // ifft (DIF)
-        HK_TRY(N::scale(s, abc, m, 3, log_m, (const Fr*)T->pw_g, minv, 1, 1));               // /m, * g^j
+        // ifft (DIF) with the "/m, * g^j" coset shift fused into its last pass
+        HK_TRY(N::passes(s, abc, m, 3, log_m, (const Fr*)T->tw_inv, T->log_table, 0, 2, &minv, (const Fr*)T->pw_g));
         HK_TRY(N::passes(s, abc, m, 3, log_m, (const Fr*)T->tw_fwd, T->log_table, 1));       // coset fft (DIT)
         Fr zinv = N::vanishing_inv_on_coset(log_m);
         hipLaunchKernelGGL((k_qap_combine<Fr>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s, abc, abc + m,
                            abc + 2 * m, zinv, m);
-        HK_TRY(N::passes(s, abc, m, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0));       // coset ifft
-        HK_TRY(N::scale(s, abc, m, 1, log_m, (const Fr*)T->pw_ginv, minv, 1, 1));
+        // coset ifft (DIF) with "/m, * g^-j" fused
+        HK_TRY(N::passes(s, abc, m, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0, 2, &minv, (const Fr*)T->pw_ginv));
         HK_HIP(hipGetLastError());
         return HK_OK;
     }
