@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--threads", type=int, default=8, help="host threads (= GPU lanes) proving concurrently")
     ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None,
+                    help="force a device index (rehearsing N > 1 ranks on a 1-GPU box with --backend gloo)")
     return ap.parse_args()
 
 
@@ -81,16 +84,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    dev = local_rank if args.device is None else args.device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     from hekaton_system_amd import capi
     from hekaton_system_amd.cp_groth16 import FrCodec, SeededRng, generate_parameters
     from hekaton_system_amd.workload import make_config
 
-    dev = local_rank
     ctx = capi.Context(args.curve, dev)
     fc = FrCodec(args.curve)
     circ = make_config(args.curve, args.config)
@@ -152,7 +157,7 @@ def main():
     barrier()
     dt = time.time() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     proofs = world * args.subcircuits * args.steps
