@@ -141,6 +141,10 @@ struct Fp {
     HK_HD static Fp mul(const Fp& a, const Fp& b) {
 #if defined(HK_USE_ASM_MUL)
         // hand-scheduled product-scanning form (gen_mont_asm.py): 128 mad+addc pairs, no pair shuffles
+#if defined(HK_EXPERIMENT_NOREDUCE)   // timing experiment only (tools/ubench): what a lazy [0,2p) form could save
+        if constexpr (P::ASM_ID == 1) { Fp r; HK_MONT_ASM_BN254_FR(r, a, b); return r; }
+        if constexpr (P::ASM_ID == 2) { Fp r; HK_MONT_ASM_BN254_FQ(r, a, b); return r; }
+#endif
         if constexpr (P::ASM_ID == 1) { Fp r; HK_MONT_ASM_BN254_FR(r, a, b); return reduce_once(r); }
         if constexpr (P::ASM_ID == 2) { Fp r; HK_MONT_ASM_BN254_FQ(r, a, b); return reduce_once(r); }
         if constexpr (P::ASM_ID == 3) { Fp r; HK_MONT_ASM_BLS12_381_FR(r, a, b); return reduce_once(r); }
