@@ -221,6 +221,33 @@ __device__ __forceinline__ void st_vec(T* p, const T& v) {
     for (int k = 0; k < (int)(sizeof(T) / 16); k++) d[k] = s[k];
 }
 
+// field-aware stores: registers may hold lazy [0,2p) values, memory is always canonical
+template <class P>
+__device__ __forceinline__ void st_vec(Fp<P>* p, const Fp<P>& v) {
+    Fp<P> c = Fp<P>::canon(v);
+    uint4* d = reinterpret_cast<uint4*>(p);
+    const uint4* s = reinterpret_cast<const uint4*>(&c);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(Fp<P>) / 16); k++) d[k] = s[k];
+}
+template <class P>
+__device__ __forceinline__ void st_vec(Fp2<P>* p, const Fp2<P>& v) {
+    st_vec(&p->c0, v.c0);
+    st_vec(&p->c1, v.c1);
+}
+template <class F>
+__device__ __forceinline__ void st_vec(Affine<F>* p, const Affine<F>& v) {
+    st_vec(&p->x, v.x);
+    st_vec(&p->y, v.y);
+}
+template <class F>
+__device__ __forceinline__ void st_vec(XYZZ<F>* p, const XYZZ<F>& v) {
+    st_vec(&p->x, v.x);
+    st_vec(&p->y, v.y);
+    st_vec(&p->zz, v.zz);
+    st_vec(&p->zzz, v.zzz);
+}
+
 // largest b in [0, NB) with start[b] <= pos   (pos < start[NB])
 __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u32 NB, u32 pos) {
     u32 lo = 0, hi = NB;   // invariant: start[lo] <= pos < start[hi]

@@ -32,7 +32,8 @@ __device__ __forceinline__ Fr fr_load(const Fr* p) {
     return r;
 }
 template <class Fr>
-__device__ __forceinline__ void fr_store(Fr* p, const Fr& r) {
+__device__ __forceinline__ void fr_store(Fr* p, const Fr& lazy) {
+    Fr r = Fr::canon(lazy);                            // memory is always canonical
     uint4* d = reinterpret_cast<uint4*>(p);
     d[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
     d[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
