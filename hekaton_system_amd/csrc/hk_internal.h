@@ -119,7 +119,7 @@ struct hk_ctx {
     size_t max_lanes = 8;
     hk::NttTables* ntt = nullptr;
     hk_timings last;
-    uint32_t max_lanes0 = 196608;   // level-0 accumulate lanes: 3 waves/SIMD x 1024 SIMDs x 64
+    uint32_t max_lanes0 = 262144;   // level-0 accumulate lanes: 4 waves/SIMD x 1024 SIMDs x 64
 };
 
 struct hk_pk {

@@ -261,7 +261,7 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
 // occupancy the accumulate kernel is compiled for (waves per SIMD): the 8-limb G1 kernel fits 168
 // VGPRs without spilling (3 waves); wider coordinates keep the compiler's default
 template <class F> struct AccumOcc { static constexpr int waves = 1; };
-template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 3 : 2; };
+template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 4 : 2; };
 template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = P::N <= 8 ? 2 : 1; };   // ubench: 2.9 vs 2.4 Gadd/s
 
 // ---- level 0: equal slices of the sorted entry list, mixed adds into registers ---------------------
@@ -285,11 +285,13 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
     u32 first_key = b;
     u32 boundary = start[b + 1];
     XYZZ<F> acc = XYZZ<F>::inf();
-    XYZZ<F> head = XYZZ<F>::inf();
+    // boundary partials go straight to memory when they become known (keeping a second XYZZ value
+    // live across the loop costs 32+ VGPRs, i.e. a wave of occupancy)
+    st_vec(&ppts[2 * t], XYZZ<F>::inf());
     for (; pos < end; pos++) {
         if (pos == boundary) {
             // bucket b ended exactly here
-            if (first && head_partial) head = acc;
+            if (first && head_partial) st_vec(&ppts[2 * t], acc);
             else st_vec(&buckets[b], acc);
             first = false;
             acc = XYZZ<F>::inf();
@@ -306,14 +308,13 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
         }
     }
     bool tail_partial = end < boundary;     // bucket b continues in the next lane's slice
-    XYZZ<F> tail = XYZZ<F>::inf();
-    if (first && head_partial) head = acc;              // single run that began before this slice
-    else if (tail_partial) tail = acc;
+    bool is_tail = false;
+    if (first && head_partial) st_vec(&ppts[2 * t], acc);          // single run that began before this slice
+    else if (tail_partial) is_tail = true;
     else st_vec(&buckets[b], acc);
     pkeys[2 * t] = first_key;
     pkeys[2 * t + 1] = b;
-    st_vec(&ppts[2 * t], head);
-    st_vec(&ppts[2 * t + 1], tail);
+    st_vec(&ppts[2 * t + 1], is_tail ? acc : XYZZ<F>::inf());
 }
 
 // ---- levels >= 1: segmented reduction of boundary partials ---------------------------------------------
