@@ -262,7 +262,7 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
 // VGPRs without spilling (3 waves); wider coordinates keep the compiler's default
 template <class F> struct AccumOcc { static constexpr int waves = 1; };
 template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 4 : 2; };
-template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = P::N <= 8 ? 2 : 1; };   // ubench: 2.9 vs 2.4 Gadd/s
+template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = 1; };
 
 // ---- level 0: equal slices of the sorted entry list, mixed adds into registers ---------------------
 // The sorted list was built for `n_entries` scalars per group; this base table has `n_bases` bases per
@@ -471,7 +471,7 @@ inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) 
     }
     p.n_levels = k + 1;
     // sort workgroups: enough of them to fill 256 CUs, chunks of at least 1024 scalars
-    u32 chunk = (n + 511) / 512;
+    u32 chunk = (n + 511) / 512;     // (n/128 measured slower: the scatter needs >= 2 workgroups per CU)
     if (chunk < 1024) chunk = 1024;
     p.chunk = chunk;
     p.K = p.B >= 8 ? 8 : p.B;
