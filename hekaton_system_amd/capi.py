@@ -48,7 +48,7 @@ class hk_timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in
                 ("total_ms", "digits_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "msm_l_ms",
                  "witness_map_ms", "msm_h_ms", "finish_ms", "accum_kernel_ms")] + \
-               [("accum_kernel_launches", C.c_uint32)]
+               [("accum_kernel_launches", C.c_uint32), ("accum_h_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

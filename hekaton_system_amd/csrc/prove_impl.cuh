@@ -619,7 +619,8 @@ hk_status Ops<C>::commit(hk_ctx* ctx, const hk_pk* h, size_t stage, const void* 
     Affine<Fq>* aff = L->alloc_n<Affine<Fq>>(1);
     if (!res || !aff) return HK_ERR_NOMEM;
     HK_TRY(MsmSort<Fr>::run(s, p, (const u32*)sc, 1, sb));
-    HK_TRY(MsmRun<Fq>::run(s, p, pk->ck_tab[stage], (u32)(n + 1), 0, sb, rb, res, nullptr, nullptr));
+    HK_TRY(MsmRun<Fq>::run(s, p, pk->ck_tab[stage], (u32)(n + 1), 0, sb, rb, res, prof ? L->ev[20] : nullptr,
+                           prof ? L->ev[21] : nullptr));
     HK_TRY(MsmRun<Fq>::to_affine(s, res, aff, 1));
     HK_HIP(hipMemcpyAsync(out, aff, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
     if (prof) HK_HIP(hipEventRecord(L->ev[1], s));
@@ -627,6 +628,8 @@ hk_status Ops<C>::commit(hk_ctx* ctx, const hk_pk* h, size_t stage, const void* 
     if (prof) {
         memset(&L->timings, 0, sizeof(L->timings));
         L->timings.total_ms = ev_ms(L->ev[0], L->ev[1]);
+        L->timings.accum_kernel_ms = ev_ms(L->ev[20], L->ev[21]);
+        L->timings.accum_kernel_launches = 1;
     }
     return HK_OK;
 }
@@ -717,11 +720,14 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     for (int k = 0; k < 3; k++) HK_HIP(hipStreamWaitEvent(ax[k], ev_sorted, 0));
     HK_TRY(MsmRun<Fq2>::run(ax[1], pz, pk->b2_tab, pk->n_ext, 0, sb, rb2, res2, nullptr, nullptr));
     HK_HIP(hipEventRecord(ev[4], ax[1]));                                      // B2 done
-    HK_TRY(MsmRun<Fq>::run(ax[0], pz, pk->b1_tab, pk->n_ext, 0, sb, rbB1, res1 + 1, nullptr, nullptr));
+    HK_TRY(MsmRun<Fq>::run(ax[0], pz, pk->b1_tab, pk->n_ext, 0, sb, rbB1, res1 + 1, prof ? ev[22] : nullptr,
+                           prof ? ev[23] : nullptr));
     HK_HIP(hipEventRecord(ev[3], ax[0]));                                      // B1 done
-    HK_TRY(MsmRun<Fq>::run(ax[2], pz, pk->l_tab, pk->l_n, pk->l_off, sb, rbL, res1 + 2, nullptr, nullptr));
+    HK_TRY(MsmRun<Fq>::run(ax[2], pz, pk->l_tab, pk->l_n, pk->l_off, sb, rbL, res1 + 2, prof ? ev[24] : nullptr,
+                           prof ? ev[25] : nullptr));
     HK_HIP(hipEventRecord(ev[18], ax[2]));                                     // L done
-    HK_TRY(MsmRun<Fq>::run(s, pz, pk->a_tab, pk->n_ext, 0, sb, rbA, res1 + 0, nullptr, nullptr));
+    HK_TRY(MsmRun<Fq>::run(s, pz, pk->a_tab, pk->n_ext, 0, sb, rbA, res1 + 0, prof ? ev[26] : nullptr,
+                           prof ? ev[27] : nullptr));
     HK_TRY(mark());                                                            // ev2: A done
     // Join
     HK_HIP(hipStreamWaitEvent(s, ev[3], 0));
@@ -751,8 +757,10 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
         t.witness_map_ms = ev_ms(ev[5], ev[6]);
         t.msm_h_ms = ev_ms(ev[6], ev[7]);
         t.finish_ms = ev_ms(ev[19], ev[8]);
-        t.accum_kernel_ms = ev_ms(ev[12], ev[13]);          // H-query bucket accumulation (dominant kernel)
-        t.accum_kernel_launches = 1;
+        // k_msm_accum0<Fq> launches of this proof: H (dense) + A, B1, L (sparse)
+        t.accum_h_ms = ev_ms(ev[12], ev[13]);
+        t.accum_kernel_ms = t.accum_h_ms + ev_ms(ev[22], ev[23]) + ev_ms(ev[24], ev[25]) + ev_ms(ev[26], ev[27]);
+        t.accum_kernel_launches = 4;
     }
     return HK_OK;
 }

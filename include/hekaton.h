@@ -94,8 +94,9 @@ typedef struct {
     float witness_map_ms;  /* "R1CS to QAP witness map" prover.rs:122-125 */
     float msm_h_ms;        /* "Compute H"        prover.rs:127-130 */
     float finish_ms;       /* "Finish C" + into_affine prover.rs:135-155, committer.rs:112-114 */
-    float accum_kernel_ms; /* sum of the bucket-accumulate kernel launches (dominant kernel) */
-    uint32_t accum_kernel_launches;
+    float accum_kernel_ms; /* sum over this call's k_msm_accum0<Fq> launches (dominant kernel),  */
+    uint32_t accum_kernel_launches;  /* timed on the kernel itself; and how many launches that was */
+    float accum_h_ms;      /* the H-query launch alone (the dense one)                             */
 } hk_timings;
 
 const char* hk_status_str(hk_status s);
