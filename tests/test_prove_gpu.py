@@ -136,3 +136,28 @@ def test_prove_synthetic_two_stage(ctx_bn254):
     assert groth16.verify_proof_trapdoor(cp, cs, pk, td, proof, [kappa], r_, s_)
     assert pairing_bn254.verify_proof(pk.vk, proof, cs.instance[1:])
     zdev.free(); dpk.free()
+
+
+def test_witness_map_on_reference_circom_r1cs(ctx_bn254):
+    """The reference's own `.r1cs` known-answer blob (circom-compat/src/lib.rs:549-606) as the matrix input
+    path: hekaton_system_amd.circom -> hk_csr -> hk_witness_map, against the oracle's restatement."""
+    import os
+    from hekaton_system_amd import circom
+    from hekaton_system_amd.cp_groth16 import FrCodec
+    here = os.path.dirname(os.path.abspath(__file__))
+    file = circom.R1CSFile.new(open(os.path.join(here, "golden", "circom_sample.r1cs"), "rb").read())
+    fc = FrCodec("bn254")
+    (A, B, C), n_inst, n_wit = file.to_csr(fc)
+    cd = Codec(BN254)
+    rnd = random.Random(11)
+    z = [1] + [rnd.randrange(BN254.r) for _ in range(n_inst + n_wit - 1)]
+
+    def rows(M):
+        rp, col, val = M
+        vals = fc.dec(val)
+        return [[(vals[k], int(col[k])) for k in range(int(rp[i]), int(rp[i + 1]))] for i in range(len(rp) - 1)]
+
+    want = groth16.witness_map_from_matrices(BN254, rows(A), rows(B), rows(C), n_inst, file.header.n_constraints, z)
+    got, m = ctx_bn254.witness_map(A, B, C, n_inst, file.header.n_constraints, cd.fr_vec_mont(z))
+    assert m == len(want) == 8
+    assert cd.fr_vec_from_mont(got) == want
