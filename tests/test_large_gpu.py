@@ -142,3 +142,41 @@ def test_ntt_large_roundtrip_and_oracle(log_m, ctx_bn254):
     ctx_bn254.ntt(dev, log_m, inverse=True, coset=True)
     assert np.array_equal(dev.to_host(), x)
     dev.free()
+
+
+def test_concurrent_lanes_match_sequential_and_are_deterministic(ctx_bn254):
+    """compute_responses proves from several OS threads (mpi-snark/src/bin/node.rs:745-795): 8 host threads on
+    one context must give, for every subcircuit, exactly the bytes a lone sequential call gives — also a
+    determinism check (the digit sort uses atomics, the proof must not depend on their order)."""
+    from concurrent.futures import ThreadPoolExecutor
+    fc = FrCodec("bn254")
+    circ = make_config("bn254", "big-merkle-4x1")
+    pk, _td = generate_parameters(circ, "bn254", SeededRng(b"HEKATON2" * 4), ctx_bn254)
+    dpk = pk.upload(ctx_bn254)
+    zs, w0s = [], []
+    for k in range(4):
+        circ.set_witness_seed(500 + k)
+        zs.append(capi.DeviceBuffer.from_host(ctx_bn254, circ.full_assignment_bytes()))
+        w0s.append(circ.stage0_witness_bytes())
+    r_b, s_b, kap = fc.enc1(3), fc.enc1(5), fc.enc([7])
+
+    def one(i):
+        k = i % 4
+        com = dpk.commit(0, w0s[k], kap)
+        a, b, c = dpk.prove(zs[k], r_b, s_b, kap, n_v=circ.n_v)
+        return com.tobytes() + a.tobytes() + b.tobytes() + c.tobytes()
+
+    seq = [one(i) for i in range(4)]
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        par = list(pool.map(one, range(32)))
+    for i, p in enumerate(par):
+        assert p == seq[i % 4], i
+    assert len(set(seq)) == 4
+    for z in zs:
+        z.free()
+    dpk.free()
+
+
+def test_config0_bls12_381_bit_exact_vs_cpu_oracle(ctx_bls):
+    """Same shape on the curve BASELINE.json's north_star names: BLS12-381 (6-limb Fq)."""
+    _run_config(ctx_bls, "bls12_381", "big-merkle-4x1", check_oracle_prove=True)
