@@ -57,7 +57,7 @@ typedef uint64_t u64;
 HK_DEFINE_FIELD(Bn254FrP, HK_BN254_FR, 1)
 HK_DEFINE_FIELD(Bn254FqP, HK_BN254_FQ, 2)
 HK_DEFINE_FIELD(Bls381FrP, HK_BLS12_381_FR, 3)
-HK_DEFINE_FIELD(Bls381FqP, HK_BLS12_381_FQ, 0)      // 12 limbs: C++ path
+HK_DEFINE_FIELD(Bls381FqP, HK_BLS12_381_FQ, 4)      // 12 limbs: tied-operand asm form
 
 // ---- prime field ---------------------------------------------------------------------------
 template <class P>
@@ -184,6 +184,7 @@ struct Fp {
         if constexpr (P::ASM_ID == 1) { Fp r; HK_MONT_ASM_BN254_FR(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
         if constexpr (P::ASM_ID == 2) { Fp r; HK_MONT_ASM_BN254_FQ(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
         if constexpr (P::ASM_ID == 3) { Fp r; HK_MONT_ASM_BLS12_381_FR(r, a, b); return reduce_once(r); }
+        if constexpr (P::ASM_ID == 4) { Fp r; HK_MONT_ASM_BLS12_381_FQ(r, a, b); return reduce_once(r); }
 #endif
         u32 t[N + 1];
         HK_UNROLL for (int i = 0; i <= N; i++) t[i] = 0;

@@ -83,13 +83,80 @@ def gen_block(name, p, n):
 """ % dict(name=name, decl=decl, body=body, outs=outs, ins=ins, clob=clob, store=store), len(L)
 
 
+M_BASE = 8                                    # v8.. hold the quotient digits m_j of the tied (12-limb) form
+
+
+def gen_block_tied(name, p, n):
+    """Variant for fields whose 3n registers exceed the 30-operand limit of an asm statement: the a-limbs are
+    read-write operands that receive the result (a_j is dead exactly when t_j is produced), the quotient
+    digits live in clobbered physical VGPRs v8.., so only 2n operands are declared."""
+    inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+    limbs = [(p >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+    TA = lambda i: "%%%d" % i                  # "+v": a_i in, t_i out
+    B = lambda i: "%%%d" % (n + i)
+    M = lambda i: "v%d" % (M_BASE + i)
+    P = lambda i: "s%d" % (SBASE + i)
+    SINV = "s%d" % (SBASE + n)
+    L = []
+    for i, l in enumerate(limbs):
+        L.append("s_mov_b32 %s, 0x%08x" % (P(i), l))
+    L.append("s_mov_b32 %s, 0x%08x" % (SINV, inv))
+    for r in (ACC_LO, ACC_HI, ACC2):
+        L.append("v_mov_b32 %s, 0" % r)
+
+    def mac(x, y):
+        L.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, ACC))
+        L.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (ACC2, ACC2))
+
+    def shift():
+        L.append("v_mov_b32 %s, %s" % (ACC_LO, ACC_HI))
+        L.append("v_mov_b32 %s, %s" % (ACC_HI, ACC2))
+        L.append("v_mov_b32 %s, 0" % ACC2)
+
+    for i in range(n):
+        for j in range(i):
+            mac(TA(j), B(i - j))
+            mac(M(j), P(i - j))
+        mac(TA(i), B(0))
+        L.append("v_mul_lo_u32 %s, %s, %s" % (M(i), ACC_LO, SINV))
+        mac(M(i), P(0))
+        shift()
+    for i in range(n, 2 * n):
+        for j in range(i - n + 1, n):
+            mac(TA(j), B(i - j))
+            mac(M(j), P(i - j))
+        L.append("v_mov_b32 %s, %s" % (TA(i - n), ACC_LO))      # a_{i-n} is dead from this column on
+        if i < 2 * n - 1:
+            shift()
+    body = "\\n\\t".join(L)
+    outs = ", ".join('"+&v"(t%d)' % i for i in range(n))
+    ins = ", ".join('"v"(b.v[%d])' % i for i in range(n))
+    clob = ", ".join('"%s"' % c for c in ["vcc", ACC_LO, ACC_HI, ACC2] + ["v%d" % (M_BASE + i) for i in range(n)] +
+                     ["s%d" % (SBASE + i) for i in range(n + 1)])
+    decl = "    u32 " + ", ".join("t%d = a.v[%d]" % (i, i) for i in range(n)) + ";"
+    store = " ".join("r.v[%d] = t%d;" % (i, i) for i in range(n))
+    return """
+// %(name)s: r = a * b * R^-1 mod p  (result in [0, 2p), caller reduces once) — tied-operand form
+#define HK_MONT_ASM_%(name)s(r, a, b)                                                   \\
+    do {                                                                                 \\
+    %(decl)s                                                                             \\
+        asm("%(body)s"                                                                   \\
+            : %(outs)s                                                                   \\
+            : %(ins)s                                                                    \\
+            : %(clob)s);                                                                 \\
+        %(store)s                                                                        \\
+    } while (0)
+""" % dict(name=name, decl=decl, body=body, outs=outs, ins=ins, clob=clob, store=store), len(L)
+
+
 def main(path):
     out = ["/* GENERATED by gen_mont_asm.py — do not edit. */", "#pragma once", ""]
     for cname, c in CURVES.items():
         for fname, p, n in (("FR", c["r"], c["fr_n"]), ("FQ", c["q"], c["fq_n"])):
-            if n != 8:
-                continue          # 12-limb fields exceed the 30-operand limit of one asm statement
-            blk, cnt = gen_block("%s_%s" % (cname, fname), p, n)
+            if n == 8:
+                blk, cnt = gen_block("%s_%s" % (cname, fname), p, n)
+            else:
+                blk, cnt = gen_block_tied("%s_%s" % (cname, fname), p, n)
             out.append("/* %d instructions */" % cnt)
             out.append(blk)
     with open(path, "w") as f:
