@@ -25,7 +25,7 @@
 #define HK_UNROLL
 #endif
 
-// Lazy reduction (device code only): values of 8-limb fields with two spare bits live in [0, 2p) while
+// Lazy reduction (device code only): values of fields with two spare bits (4p <= R) live in [0, 2p) while
 // they are in registers — the Montgomery product of two such values is again < 2p when 4p <= R, so the
 // conditional subtraction after every product disappears (ubench: +12 % mults/s, +8 % mixed adds/s).
 // Everything written to memory is canonical [0, p): see canon() and the st_vec / fr_store helpers.
@@ -48,7 +48,7 @@ typedef uint64_t u64;
         static constexpr int ASM_ID = ASMID;                                 \
         static constexpr u32 MOD[PREFIX##_N] = PREFIX##_MOD;                 \
         static constexpr u32 MOD2[PREFIX##_N] = PREFIX##_MOD2;               \
-        static constexpr bool LAZY = HK_LAZY_DEVICE && PREFIX##_LAZY_OK && PREFIX##_N <= 8; \
+        static constexpr bool LAZY = HK_LAZY_DEVICE && PREFIX##_LAZY_OK;                     \
         static constexpr u32 ONE[PREFIX##_N] = PREFIX##_ONE;                 \
         static constexpr u32 R2[PREFIX##_N] = PREFIX##_R2;                   \
         static constexpr u32 INV = PREFIX##_INV32;                           \
@@ -184,7 +184,7 @@ struct Fp {
         if constexpr (P::ASM_ID == 1) { Fp r; HK_MONT_ASM_BN254_FR(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
         if constexpr (P::ASM_ID == 2) { Fp r; HK_MONT_ASM_BN254_FQ(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
         if constexpr (P::ASM_ID == 3) { Fp r; HK_MONT_ASM_BLS12_381_FR(r, a, b); return reduce_once(r); }
-        if constexpr (P::ASM_ID == 4) { Fp r; HK_MONT_ASM_BLS12_381_FQ(r, a, b); return reduce_once(r); }
+        if constexpr (P::ASM_ID == 4) { Fp r; HK_MONT_ASM_BLS12_381_FQ(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
 #endif
         u32 t[N + 1];
         HK_UNROLL for (int i = 0; i <= N; i++) t[i] = 0;
