@@ -447,18 +447,11 @@ k_msm_build_tables(Affine<F>* __restrict__ table, u32 n, u32 F_groups, u32 shift
 #endif  // __HIPCC__
 
 // ---- host-side planning -----------------------------------------------------------------------------
-inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) {
-    MsmPlan p;
-    p.n = n;
-    p.c = c;
-    p.B = 1u << (c - 1);
-    p.W = (fr_bits + 2 + c - 1) / c;
-    if (WP > p.W) WP = p.W;
-    p.WP = WP;
-    p.F = (p.W + WP - 1) / WP;
-    p.NB = WP * p.B;
+// (re)derive the accumulate schedule of a plan for a kernel flavour that keeps `max_lanes0` lanes resident
+// (lanes = waves/SIMD the kernel is compiled for x 1024 SIMDs x 64): one full round of equal slices
+inline void msm_set_lanes(MsmPlan& p, u32 max_lanes0) {
     p.Lmin0 = 32;
-    u64 emax = (u64)n * p.W;
+    u64 emax = (u64)p.n * p.W;
     u64 t0 = (emax + p.Lmin0 - 1) / p.Lmin0;
     if (t0 > max_lanes0) t0 = max_lanes0;
     if (t0 == 0) t0 = 1;
@@ -470,6 +463,19 @@ inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) 
         k++;
     }
     p.n_levels = k + 1;
+}
+
+inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) {
+    MsmPlan p;
+    p.n = n;
+    p.c = c;
+    p.B = 1u << (c - 1);
+    p.W = (fr_bits + 2 + c - 1) / c;
+    if (WP > p.W) WP = p.W;
+    p.WP = WP;
+    p.F = (p.W + WP - 1) / WP;
+    p.NB = WP * p.B;
+    msm_set_lanes(p, max_lanes0);
     // sort workgroups: enough of them to fill 256 CUs, chunks of at least 1024 scalars
     u32 chunk = (n + 511) / 512;     // (n/128 measured slower: the scatter needs >= 2 workgroups per CU)
     if (chunk < 1024) chunk = 1024;

@@ -46,8 +46,18 @@ hk_status MsmSort<Fr>::run(hipStream_t s, const MsmPlan& p, const u32* scalars_d
     return HK_OK;
 }
 
+// accumulate schedule for this coordinate field: as many lanes as the kernel keeps resident
+// (AccumOcc<F>::waves per SIMD x 1024 SIMDs x 64), so the sorted list is consumed in ONE balanced round
 template <class F>
-hk_status MsmRun<F>::alloc(Lane* L, const MsmPlan& p, Bufs* out) {
+static inline MsmPlan msm_lane_plan(const MsmPlan& p0) {
+    MsmPlan p = p0;
+    msm_set_lanes(p, (u32)AccumOcc<F>::waves * 65536u);
+    return p;
+}
+
+template <class F>
+hk_status MsmRun<F>::alloc(Lane* L, const MsmPlan& p0, Bufs* out) {
+    const MsmPlan p = msm_lane_plan<F>(p0);
     out->buckets = L->alloc_n<XYZZ<F>>(p.NB);
     size_t n0 = 2ull * p.T[0];
     size_t n1 = p.n_levels > 1 ? 2ull * p.T[1] : 2;
@@ -64,9 +74,10 @@ hk_status MsmRun<F>::alloc(Lane* L, const MsmPlan& p, Bufs* out) {
 }
 
 template <class F>
-hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p, const Affine<F>* table, u32 n_bases, u32 idx_off,
+hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p0, const Affine<F>* table, u32 n_bases, u32 idx_off,
                          const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
                          hipEvent_t ev0, hipEvent_t ev1) {
+    const MsmPlan p = msm_lane_plan<F>(p0);
     HK_HIP(hipMemsetAsync(b.buckets, 0, sizeof(XYZZ<F>) * p.NB, s));
     // with profiling on, ev0/ev1 take the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), so
     // the figure agrees with rocprofv3's kernel trace even when other lanes share the hardware queues
