@@ -1,0 +1,101 @@
+"""GPU: edge cases of the C ABI that the reference's domain has — empty / ragged inputs, size-1 domains,
+single-stage keys, wrong lengths (the reference asserts / unwraps there), repeated uploads."""
+import random
+
+import numpy as np
+import pytest
+
+from hekaton_system_amd import capi
+from oracle.pyref import curve, groth16
+from oracle.pyref.codec import Codec
+from oracle.pyref.params import BN254
+from oracle.pyref.poly import Domain
+from tests.util import synthetic_r1cs, pk_upload_from_oracle, csr_from_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ntt_size_one_and_two(ctx_bn254):
+    cd = Codec(BN254)
+    for log_m in (0, 1):
+        x = [7, 9][: 1 << log_m]
+        for inv, coset in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            buf = cd.fr_vec_mont(x)
+            ctx_bn254.ntt(buf, log_m, inverse=inv, coset=coset)
+            dom = Domain(BN254, 1 << log_m)
+            g = BN254.fr_generator
+            want = {(0, 0): dom.fft, (1, 0): dom.ifft}.get((inv, coset), None)
+            want = want(x) if want else (dom.coset_fft(x, g) if not inv else dom.coset_ifft(x, g))
+            assert cd.fr_vec_from_mont(buf) == want
+
+
+def test_msm_all_zero_scalars_and_all_infinity_bases(ctx_bn254):
+    cd = Codec(BN254)
+    G = curve.G1(BN254)
+    bases = [G.mul(G.gen, k + 2) for k in range(40)]
+    assert cd.g1_from(ctx_bn254.msm_g1(cd.g1_vec(bases), cd.fr_vec_mont([0] * 40))) is None
+    assert cd.g1_from(ctx_bn254.msm_g1(cd.g1_vec([None] * 40), cd.fr_vec_mont(list(range(1, 41))))) is None
+    # sum cancels exactly: P*(r-1) + P = infinity
+    assert cd.g1_from(ctx_bn254.msm_g1(cd.g1_vec([bases[0], bases[0]]), cd.fr_vec_mont([BN254.r - 1, 1]))) is None
+
+
+def test_prove_with_empty_stage0_and_bad_lengths(ctx_bn254):
+    """A two-stage key whose stage 0 allocates no witnesses (an empty subtrace) must still commit
+    (com = kappa * delta) and prove; wrong n_v / h_len are length errors (prover.rs:128, committer.rs:83)."""
+    cp = BN254
+    cd = Codec(cp)
+    rnd = random.Random(99)
+    cs = groth16.R1CS(cp.r)
+    cs.begin_stage(); cs.end_stage()                       # empty stage 0
+    cs.begin_stage()
+    x = cs.alloc_instance(5)
+    w = cs.alloc_witness(25)
+    cs.enforce([(1, x)], [(1, x)], [(1, w)])
+    cs.end_stage()
+    assert cs.is_satisfied()
+    pk, td = groth16.generate_parameters(cp, cs, 3, 5, 7, [11, 13], 17, 2, 3)
+    dpk = pk_upload_from_oracle(ctx_bn254, cd, pk, cs)
+    kappa, r_, s_ = 21, 22, 23
+    com = cd.g1_from(dpk.commit(0, np.zeros(0, np.uint8), cd.fr_vec_mont([kappa]), n=0))
+    assert com == groth16.commit(cp, cs, pk, 0, kappa)
+    a, b, c = dpk.prove(cd.fr_vec_mont(cs.full_assignment()), cd.fr_vec_mont([r_]), cd.fr_vec_mont([s_]),
+                        cd.fr_vec_mont([kappa]))
+    proof = groth16.Proof(cd.g1_from(a), cd.g2_from(b), cd.g1_from(c), [com])
+    assert groth16.verify_proof_trapdoor(cp, cs, pk, td, proof, [kappa], r_, s_)
+    with pytest.raises(capi.HekatonError) as e:              # assignment of the wrong length
+        dpk.prove(cd.fr_vec_mont(cs.full_assignment() + [1]), cd.fr_vec_mont([r_]), cd.fr_vec_mont([s_]),
+                  cd.fr_vec_mont([kappa]))
+    assert e.value.status == capi.HK_ERR_LEN
+    dpk.free()
+    # h_g one element short -> the prover.rs:128 assert, reported at upload
+    A, B, C = cs.matrices()
+    with pytest.raises(capi.HekatonError) as e:
+        ctx_bn254.pk_upload(a_g=cd.g1_vec(pk.a_g), b_g=cd.g1_vec(pk.b_g), b_h=cd.g2_vec(pk.b_h),
+                            h_g=cd.g1_vec(pk.h_g[:-1]), ck_stages=[cd.g1_vec(v) for v in pk.ck.deltas_abc_g],
+                            deltas_g=cd.g1_vec(pk.deltas_g), last_delta_h=cd.g2_vec([pk.last_delta_h()]),
+                            alpha_g=cd.g1_vec([pk.vk.alpha_g]), beta_g=cd.g1_vec([pk.beta_g]),
+                            beta_h=cd.g2_vec([pk.vk.beta_h]),
+                            matrices=(csr_from_rows(cd, A), csr_from_rows(cd, B), csr_from_rows(cd, C)),
+                            n_inst=cs.num_instance, n_constraints=cs.num_constraints)
+    assert e.value.status == capi.HK_ERR_LEN
+
+
+def test_two_keys_resident_at_once(ctx_bn254):
+    """Several proving-key classes live on the device together (big-merkle has 5, tree_hash_circuit.rs:192-216)."""
+    cp = BN254
+    cd = Codec(cp)
+    rnd = random.Random(5)
+    keys = []
+    for k in range(2):
+        cs = synthetic_r1cs(cp, rnd, n_inst=4, n_free=20 + 10 * k, n_c=40 + 30 * k, two_stage_split=8)
+        pk, td = groth16.generate_parameters(cp, cs, 3 + k, 5, 7, [11, 13], 17 + k, 2, 3)
+        keys.append((cs, pk, td, pk_upload_from_oracle(ctx_bn254, cd, pk, cs)))
+    for cs, pk, td, dpk in reversed(keys):
+        kappa, r_, s_ = 1 + rnd.randrange(cp.r - 1), rnd.randrange(cp.r), rnd.randrange(cp.r)
+        com = cd.g1_from(dpk.commit(0, cd.fr_vec_mont(cs.stage_witness(0)), cd.fr_vec_mont([kappa])))
+        a, b, c = dpk.prove(cd.fr_vec_mont(cs.full_assignment()), cd.fr_vec_mont([r_]), cd.fr_vec_mont([s_]),
+                            cd.fr_vec_mont([kappa]))
+        proof = groth16.Proof(cd.g1_from(a), cd.g2_from(b), cd.g1_from(c), [com])
+        assert groth16.verify_proof_trapdoor(cp, cs, pk, td, proof, [kappa], r_, s_)
+    for *_, dpk in keys:
+        dpk.free()
