@@ -58,7 +58,7 @@ class hk_timings(C.Structure):
 EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk_ctx_sync",
            "hk_ctx_set_profiling", "hk_ctx_last_timings", "hk_ctx_sizes", "hk_dev_alloc", "hk_dev_free",
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
-           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2"]
+           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2"]
 
 _lib = None
 
@@ -92,6 +92,8 @@ def load():
     lib.hk_ntt.argtypes = [vp, vp, C.c_uint, i, i]
     for f in (lib.hk_fixed_base_g1, lib.hk_fixed_base_g2):
         f.argtypes = [vp, vp, vp, sz, i, vp]
+    for f in (lib.hk_scalar_pairing_g1, lib.hk_scalar_pairing_g2):
+        f.argtypes = [vp, vp, vp, sz, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -219,6 +221,15 @@ class Context:
         res = out if out is not None else np.zeros(n * pb, dtype=np.uint8)
         check(fn(self.handle, base.ctypes.data, ptr(scalars), n, int(montgomery), ptr(res)), fn.__name__)
         return res
+
+    def scalar_pairing(self, group, points, scalars, n=None):
+        """`scalar_pairing` (distributed-prover/src/pairing_ops.rs:32-39): out[i] = scalars[i] * points[i]."""
+        pb = self.g1_bytes if group == 1 else self.g2_bytes
+        n = n if n is not None else len(scalars) // self.fr_bytes
+        fn = self.lib.hk_scalar_pairing_g1 if group == 1 else self.lib.hk_scalar_pairing_g2
+        out = np.zeros(n * pb, dtype=np.uint8)
+        check(fn(self.handle, ptr(points), ptr(scalars), n, out.ctypes.data), fn.__name__)
+        return out
 
     def ntt(self, data, log_m, inverse=False, coset=False):
         """In-place on `data` (numpy uint8 array of 2^log_m Fr or a DeviceBuffer)."""

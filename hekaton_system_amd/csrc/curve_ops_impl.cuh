@@ -104,11 +104,12 @@ struct Ops {
                            const void*, size_t, void*, void*, void*);
     static void ctx_release(hk_ctx*);
     static hk_status fixed_base(hk_ctx*, int, const void*, const void*, size_t, int, void*);
+    static hk_status scalar_pairing(hk_ctx*, int, const void*, const void*, size_t, void*);
 
     static const CurveOps* table() {
         static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
-                                   &ctx_release, &fixed_base};
+                                   &ctx_release, &fixed_base, &scalar_pairing};
         return &t;
     }
 };

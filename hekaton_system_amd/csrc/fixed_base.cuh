@@ -56,6 +56,18 @@ k_fb_mul(const Affine<F>* __restrict__ table, const Fr* __restrict__ scalars, in
     st_vec(&out[i], acc);
 }
 
+// out[i] = scalars[i] * points[i] (XYZZ), one lane per element, plain double-and-add over the canonical scalar
+// (`scalar_pairing`, distributed-prover/src/pairing_ops.rs:32-39; N = #subcircuits <= 1024, latency-bound)
+template <class Fr, class F>
+__global__ void __launch_bounds__(64)
+k_scalar_mul_each(const Affine<F>* __restrict__ pts, const Fr* __restrict__ scalars, u32 n, XYZZ<F>* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = Fr::from_mont(ld_vec(&scalars[i]));
+    XYZZ<F> p = XYZZ<F>::from_affine(ld_vec(&pts[i]));
+    st_vec(&out[i], ec_mul_limbs(p, s.v));
+}
+
 // XYZZ -> affine for n points, FB_CHUNK per lane, one field inversion per lane.
 // scratch: n coordinate-field elements (prefix products of zzz).
 template <class F>

@@ -217,6 +217,14 @@ hk_status hk_fixed_base_g2(hk_ctx* ctx, const void* base, const void* scalars, s
     if (!ctx || !base || (n && (!scalars || !out))) return HK_ERR_ARG;
     return ctx->ops->fixed_base(ctx, 2, base, scalars, n, mont, out);
 }
+hk_status hk_scalar_pairing_g1(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out) {
+    if (!ctx || (n && (!points || !scalars || !out))) return HK_ERR_ARG;
+    return ctx->ops->scalar_pairing(ctx, 1, points, scalars, n, out);
+}
+hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out) {
+    if (!ctx || (n && (!points || !scalars || !out))) return HK_ERR_ARG;
+    return ctx->ops->scalar_pairing(ctx, 2, points, scalars, n, out);
+}
 hk_status hk_ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int coset) {
     if (!ctx || !data) return HK_ERR_ARG;
     return ctx->ops->ntt(ctx, data, log_m, inverse, coset);

@@ -103,6 +103,7 @@ struct CurveOps {
     void (*ctx_release)(hk_ctx*);
     hk_status (*fixed_base)(hk_ctx*, int group, const void* base, const void* scalars, size_t n, int mont,
                             void* out);
+    hk_status (*scalar_pairing)(hk_ctx*, int group, const void* points, const void* scalars, size_t n, void* out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

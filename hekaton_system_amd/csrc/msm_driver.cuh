@@ -44,6 +44,9 @@ struct MsmRun {
     static hk_status fixed_base(hipStream_t s, const Affine<F>* base, const void* scalars, int is_mont,
                                 u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out);
     static hk_status batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, F* pref, u32 n);
+    // out[i] = scalars[i] * points[i] (pairing_ops.rs:32-39); xy / pref: n-element scratch
+    static hk_status scalar_mul_each(hipStream_t s, const Affine<F>* pts, const void* scalars_mont, u32 n,
+                                     XYZZ<F>* xy, F* pref, Affine<F>* out);
 };
 
 }  // namespace hk

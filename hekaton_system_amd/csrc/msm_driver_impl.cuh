@@ -133,6 +133,17 @@ hk_status MsmRun<F>::batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* o
 }
 
 template <class F>
+hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const void* scalars_mont, u32 n,
+                                     XYZZ<F>* xy, F* pref, Affine<F>* out) {
+    typedef typename ScalarOf<F>::type Fr;
+    if (n == 0) return HK_OK;
+    hipLaunchKernelGGL((k_scalar_mul_each<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, pts, (const Fr*)scalars_mont,
+                       n, xy);
+    HK_HIP(hipGetLastError());
+    return batch_affine(s, xy, out, pref, n);
+}
+
+template <class F>
 hk_status MsmRun<F>::fixed_base(hipStream_t s, const Affine<F>* base, const void* scalars, int is_mont,
                                 u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out) {
     typedef typename ScalarOf<F>::type Fr;

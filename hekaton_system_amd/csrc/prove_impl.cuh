@@ -534,6 +534,35 @@ hk_status Ops<C>::fixed_base(hk_ctx* ctx, int group, const void* base, const voi
 }
 
 template <class C>
+hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, const void* scalars, size_t n,
+                                 void* out) {
+    if (n == 0) return HK_OK;
+    if (n >= (1u << 28)) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    auto run = [&](auto ftag) -> hk_status {
+        typedef decltype(ftag) F;
+        size_t need = al256(n * sizeof(Affine<F>)) * 2 + al256(n * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
+                      al256(n * sizeof(F)) + 8192;
+        HK_TRY(L->reserve(need));
+        const void *pd, *sd;
+        HK_TRY(to_device(L, points, n * sizeof(Affine<F>), &pd));
+        HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sd));
+        XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
+        F* pref = L->alloc_n<F>(n);
+        bool out_dev = is_device_ptr(out);
+        Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
+        if (!xy || !pref || !od) return HK_ERR_NOMEM;
+        HK_TRY(MsmRun<F>::scalar_mul_each(L->stream, (const Affine<F>*)pd, sd, (u32)n, xy, pref, od));
+        if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+        HK_HIP(hipStreamSynchronize(L->stream));
+        return HK_OK;
+    };
+    return group == 1 ? run(Fq()) : run(Fq2());
+}
+
+template <class C>
 void Ops<C>::ctx_release(hk_ctx* ctx) {
     if (!ctx->ntt) return;
     NttTables* T = ctx->ntt;

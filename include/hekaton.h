@@ -155,6 +155,13 @@ hk_status hk_fixed_base_g1(hk_ctx* ctx, const void* base, const void* scalars, s
 hk_status hk_fixed_base_g2(hk_ctx* ctx, const void* base, const void* scalars, size_t n,
                            int scalars_are_montgomery, void* out);
 
+/* N independent scalar multiplications out[i] = scalars[i] * points[i], batch-normalised to affine —
+ * replaces `scalar_pairing` (distributed-prover/src/pairing_ops.rs:32-39: `*si * *ri` + `normalize_batch`),
+ * called 8x per aggregation with N = #subcircuits (aggregation.rs:236-242,289-310).
+ * points [h|d]: n packed affine; scalars [h|d]: n Fr (Montgomery); out [h|d]: n packed affine. */
+hk_status hk_scalar_pairing_g1(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
+hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
+
 /* ---- proving-key residency -------------------------------------------------------------- */
 hk_status hk_pk_upload(hk_ctx* ctx, const hk_pk_desc* desc, hk_pk** out);
 void      hk_pk_free(hk_pk* pk);

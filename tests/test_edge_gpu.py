@@ -99,3 +99,25 @@ def test_two_keys_resident_at_once(ctx_bn254):
         assert groth16.verify_proof_trapdoor(cp, cs, pk, td, proof, [kappa], r_, s_)
     for *_, dpk in keys:
         dpk.free()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_scalar_pairing_like_reference(group, ctx_bn254):
+    """pairing_ops.rs:32-39 `scalar_pairing`: element-wise scalar multiplication + batch normalisation, as the
+    aggregator calls it with powers of a challenge (aggregation.rs:236-242)."""
+    cp = BN254
+    cd = Codec(cp)
+    G = curve.G1(cp) if group == 1 else curve.G2(cp)
+    rnd = random.Random(group)
+    n = 37
+    pts = [G.mul(G.gen, rnd.randrange(1, cp.r)) for _ in range(n)]
+    pts[3] = None
+    twist = rnd.randrange(cp.r)
+    scal = [pow(twist, i, cp.r) for i in range(n)]            # structured_scalar_power(num, s)
+    scal[5] = 0
+    enc = cd.g1_vec if group == 1 else cd.g2_vec
+    dec = cd.g1_from if group == 1 else cd.g2_from
+    pb = cd.g1_bytes if group == 1 else cd.g2_bytes
+    out = ctx_bn254.scalar_pairing(group, enc(pts), cd.fr_vec_mont(scal))
+    got = [dec(out[i * pb:(i + 1) * pb]) for i in range(n)]
+    assert got == [G.mul(p, s) if p is not None else None for p, s in zip(pts, scal)]
