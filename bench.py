@@ -203,7 +203,7 @@ def main():
             "config": {"workload": args.config, "curve": args.curve, "subcircuits_per_gpu_per_step": args.subcircuits,
                        "n_constraints": circ.n_c, "n_variables": circ.n_v, "domain": m,
                        "host_threads_per_gpu": args.threads, "sharding": "subcircuits/%d per rank" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accum0<Fp<Bn254FqP>> (bucket accumulation; avg over its 5 launches per subcircuit)",
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accum0<Fp<%s>> (bucket accumulation; avg over its 5 launches per subcircuit)" % ("Bn254FqP" if args.curve == "bn254" else "Bls381FqP"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
