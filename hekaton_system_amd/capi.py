@@ -58,7 +58,7 @@ class hk_timings(C.Structure):
 EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk_ctx_sync",
            "hk_ctx_set_profiling", "hk_ctx_last_timings", "hk_ctx_sizes", "hk_dev_alloc", "hk_dev_free",
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
-           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2"]
+           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert"]
 
 _lib = None
 
@@ -94,6 +94,7 @@ def load():
         f.argtypes = [vp, vp, vp, sz, i, vp]
     for f in (lib.hk_scalar_pairing_g1, lib.hk_scalar_pairing_g2):
         f.argtypes = [vp, vp, vp, sz, vp]
+    lib.hk_field_convert.argtypes = [vp, i, vp, vp, sz, i]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -229,6 +230,17 @@ class Context:
         fn = self.lib.hk_scalar_pairing_g1 if group == 1 else self.lib.hk_scalar_pairing_g2
         out = np.zeros(n * pb, dtype=np.uint8)
         check(fn(self.handle, ptr(points), ptr(scalars), n, out.ctypes.data), fn.__name__)
+        return out
+
+    def field_convert(self, which, data, to_mont):
+        """Montgomery <-> canonical for a packed array of Fr (`which` = 0) or Fq (1) elements: what ark-ff
+        `from_bigint` / `into_bigint` do under ark-serialize.  Returns a new numpy uint8 array."""
+        eb = self.fr_bytes if which == 0 else self.fq_bytes
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        n = data.size // eb
+        out = np.empty(n * eb, dtype=np.uint8)
+        check(self.lib.hk_field_convert(self.handle, int(which), data.ctypes.data, out.ctypes.data, n, int(to_mont)),
+              "hk_field_convert")
         return out
 
     def ntt(self, data, log_m, inverse=False, coset=False):

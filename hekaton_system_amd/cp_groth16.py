@@ -88,11 +88,10 @@ class FrCodec:
 
 # --------------------------------------------------------------------------------------- RNG
 class SeededRng:
-    """Deterministic stand-in for the reference's `ChaCha12Rng::from_seed(com_seed)` discipline
-    (distributed-prover/src/worker.rs:129-137; mpi-snark/src/worker.rs:63-66): the commitment
-    randomness is the FIRST draw of an RNG seeded with the 32-byte `com_seed`, so it can be re-derived
-    from the seed.  SHA-256 in counter mode — NOT bit-compatible with rand_chacha (wire compatibility
-    is SURVEY.md §8f row 4)."""
+    """Deterministic test RNG for the CALLER-side draws (r, s, com_seed, setup toxic waste), where the reference
+    takes any `RngCore` (prover.rs:28-29; worker.rs:91): SHA-256 in counter mode.  The one draw that is part of
+    the protocol — kappa = Fr::rand(ChaCha12Rng::from_seed(com_seed)), worker.rs:129-137 — is reproduced bit for
+    bit by `chacha.ChaCha12Rng`, which has this class's duck type and is what `worker.py` uses."""
 
     def __init__(self, seed: bytes):
         assert len(seed) == 32

@@ -105,11 +105,12 @@ struct Ops {
     static void ctx_release(hk_ctx*);
     static hk_status fixed_base(hk_ctx*, int, const void*, const void*, size_t, int, void*);
     static hk_status scalar_pairing(hk_ctx*, int, const void*, const void*, size_t, void*);
+    static hk_status field_convert(hk_ctx*, int, const void*, void*, size_t, int);
 
     static const CurveOps* table() {
         static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
-                                   &ctx_release, &fixed_base, &scalar_pairing};
+                                   &ctx_release, &fixed_base, &scalar_pairing, &field_convert};
         return &t;
     }
 };

@@ -225,6 +225,10 @@ hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scal
     if (!ctx || (n && (!points || !scalars || !out))) return HK_ERR_ARG;
     return ctx->ops->scalar_pairing(ctx, 2, points, scalars, n, out);
 }
+hk_status hk_field_convert(hk_ctx* ctx, int which, const void* in, void* out, size_t n, int to_mont) {
+    if (!ctx || (which != 0 && which != 1) || (n && (!in || !out))) return HK_ERR_ARG;
+    return ctx->ops->field_convert(ctx, which, in, out, n, to_mont);
+}
 hk_status hk_ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int coset) {
     if (!ctx || !data) return HK_ERR_ARG;
     return ctx->ops->ntt(ctx, data, log_m, inverse, coset);

@@ -104,6 +104,7 @@ struct CurveOps {
     hk_status (*fixed_base)(hk_ctx*, int group, const void* base, const void* scalars, size_t n, int mont,
                             void* out);
     hk_status (*scalar_pairing)(hk_ctx*, int group, const void* points, const void* scalars, size_t n, void* out);
+    hk_status (*field_convert)(hk_ctx*, int which, const void* in, void* out, size_t n, int to_mont);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

@@ -562,6 +562,50 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
     return group == 1 ? run(Fq()) : run(Fq2());
 }
 
+// out[i] = in[i] * R (to_mont) or in[i] / R; memory canonical either way
+template <class F>
+__global__ void k_field_convert(const F* __restrict__ in, F* __restrict__ out, size_t n, int to_mont) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F x = ld_vec(&in[i]);
+    st_vec(&out[i], to_mont ? F::to_mont(x) : F::from_mont(x));
+}
+
+template <class C>
+hk_status Ops<C>::field_convert(hk_ctx* ctx, int which, const void* in, void* out, size_t n, int to_mont) {
+    if (n == 0) return HK_OK;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    auto run = [&](auto ftag) -> hk_status {
+        typedef decltype(ftag) F;
+        const size_t CH = (size_t)1 << 24;                       // host buffers go through the lane in chunks
+        bool in_dev = is_device_ptr(in), out_dev = is_device_ptr(out);
+        HK_TRY(L->reserve(2 * al256(std::min(n, CH) * sizeof(F)) + 4096));
+        for (size_t off = 0; off < n; off += CH) {
+            size_t k = std::min(CH, n - off);
+            L->arena_off = 0;
+            const F* src = (const F*)in + off;
+            F* dst = (F*)out + off;
+            const F* sd = src;
+            if (!in_dev) {
+                F* t = L->alloc_n<F>(k);
+                if (!t) return HK_ERR_NOMEM;
+                HK_HIP(hipMemcpyAsync(t, src, k * sizeof(F), hipMemcpyHostToDevice, L->stream));
+                sd = t;
+            }
+            F* dd = out_dev ? dst : L->alloc_n<F>(k);
+            if (!dd) return HK_ERR_NOMEM;
+            hipLaunchKernelGGL(k_field_convert<F>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, L->stream, sd, dd, k, to_mont);
+            HK_HIP(hipGetLastError());
+            if (!out_dev) HK_HIP(hipMemcpyAsync(dst, dd, k * sizeof(F), hipMemcpyDeviceToHost, L->stream));
+            HK_HIP(hipStreamSynchronize(L->stream));
+        }
+        return HK_OK;
+    };
+    return which == 0 ? run(Fr()) : run(Fq());
+}
+
 template <class C>
 void Ops<C>::ctx_release(hk_ctx* ctx) {
     if (!ctx->ntt) return;

@@ -16,7 +16,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .cp_groth16 import CommitmentBuilder, Proof, SeededRng
+from .chacha import ChaCha12Rng
+from .cp_groth16 import CommitmentBuilder, Proof
 
 
 @dataclass
@@ -77,7 +78,7 @@ def process_stage0_request_get_cb(rng, pk, req, circuit):
     the randomness, return (response, commitment builder)."""
     circuit.subcircuit_idx = req.subcircuit_idx
     com_seed = rng.gen_seed()                                   # worker.rs:129
-    subcircuit_rng = SeededRng(com_seed)
+    subcircuit_rng = ChaCha12Rng(com_seed)                        # worker.rs:130
     cb = CommitmentBuilder.new(circuit, pk)
     com, _ = cb.commit(subcircuit_rng)                          # worker.rs:134-137
     return Stage0Response(req.subcircuit_idx, com, com_seed), cb
@@ -107,7 +108,7 @@ class WorkerState:
         pk = self.pk_for_idx(stage0_req.subcircuit_idx)
         resp, cb = process_stage0_request_get_cb(rng, pk, stage0_req, self.circuit_for_idx(stage0_req.subcircuit_idx))
         self.cb, self.com = cb, resp.com
-        self.com_rand = SeededRng(resp.com_seed).fr(self.r_mod)
+        self.com_rand = ChaCha12Rng(resp.com_seed).fr(self.r_mod)
         return resp
 
     def stage_1(self, rng, stage1_req):

@@ -162,6 +162,13 @@ hk_status hk_fixed_base_g2(hk_ctx* ctx, const void* base, const void* scalars, s
 hk_status hk_scalar_pairing_g1(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
 hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
 
+/* Montgomery <-> canonical conversion of n field elements (which: 0 = Fr, 1 = Fq; to_mont != 0: out = in*R mod p,
+ * else out = in/R mod p; canonical input must be < p).  in/out are host or device pointers and may alias.
+ * replaces ark-ff `into_bigint()` / `from_bigint()` as ark-serialize calls them for every field element of a key
+ * file or response (mpi-snark/src/bin/node.rs:231-237 `ProvingKeys::deserialize_uncompressed_unchecked`;
+ * mpi-snark/src/lib.rs:68-71 `serialize_to_vec`): the wire format is canonical little-endian, the ABI Montgomery. */
+hk_status hk_field_convert(hk_ctx* ctx, int which, const void* in, void* out, size_t n, int to_mont);
+
 /* ---- proving-key residency -------------------------------------------------------------- */
 hk_status hk_pk_upload(hk_ctx* ctx, const hk_pk_desc* desc, hk_pk** out);
 void      hk_pk_free(hk_pk* pk);
