@@ -82,6 +82,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    from hekaton_system_amd import capi          # first: exports GPU_MAX_HW_QUEUES before anything initialises HIP
     import torch
     import torch.distributed as dist
     dev = local_rank if args.device is None else args.device
@@ -92,7 +93,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    from hekaton_system_amd import capi
     from hekaton_system_amd.cp_groth16 import FrCodec, SeededRng, generate_parameters
     from hekaton_system_amd.workload import make_config
 

@@ -8,17 +8,18 @@
 // so the witness map never pays a bit-reversal pass: the coset/1/m scaling between the two reads its
 // exponent from the bit-reversed index, and the H-query bases are stored bit-reversed at key upload.
 //
-// Each pass keeps a tile of 2^8 rows x 8 contiguous elements (64 KiB) in LDS and runs up to 8 butterfly
-// stages there, so a 2^21-point transform is 3 HBM round trips (64*m bytes each).
+// Each pass keeps a tile of 2^11 elements (64 KiB) in LDS — 2^nst rows x 2^cols_bits contiguous elements —
+// and runs up to 11 butterfly stages there, two stages at a time in registers (radix-4 steps), so a
+// 2^21-point transform is 2 HBM round trips (64*m bytes each).
 #pragma once
 #include "field.cuh"
 
 namespace hk {
 
-constexpr int NTT_TILE_LOG_ROWS = 8;     // stages per pass
-constexpr int NTT_TILE_LOG_COLS = 3;     // 8 contiguous elements = 256 B per row
-constexpr int NTT_THREADS = 256;         // 512 measured no faster: the passes are bound by field-multiply issue, not latency
-constexpr int POW_TABLE_BITS = 10;       // g^j = T0[j & 1023] * T1[(j >> 10) & 1023] * T2[j >> 20]
+constexpr int NTT_TILE_LOG = 11;         // elements per LDS tile (2^11 x 32 B = 64 KiB, two tiles per CU)
+constexpr int NTT_THREADS = 512;         // one radix-4 step of a full tile = one quad per thread
+constexpr int POW_TABLE_BITS = 11;       // g^j = T0[j & 2047] * T1[(j >> 11) & 2047] * T2[j >> 22]
+constexpr int POW_TABLE_SIZE = 1 << POW_TABLE_BITS;
 
 #if defined(__HIPCC__)
 
@@ -50,80 +51,126 @@ __global__ void k_pow_table(Fr* __restrict__ tw, const Fr* __restrict__ sq, u32 
     fr_store(&tw[i], acc);
 }
 
-// One pass of `nst` butterfly stages [lo, lo+nst) on a transform of size 2^logn, in place.
-//   DIF (dit == 0): stages run from high to low, butterfly (u, v) -> (u + v, (u - v) * w)
-//   DIT (dit == 1): stages run from low to high, butterfly (u, v) -> (u + v*w, u - v*w)
-// tw: table of w_M^i, i < M/2, M = 2^log_table.  Batched over blockIdx.y (vectors `stride_vec` apart).
-// Optional fused epilogue (post != 0): every element is multiplied by `scale` and, when post == 2, also by
-// g^bitrev(index) from the 3x1024 power tables `pw` before it is stored — the "/m and coset shift"
-// step that follows a DIF chain in the witness map, so it costs no extra HBM round trip.
+// g^j from the three-level power tables: T0[j & 2047] * T1[(j >> 11) & 2047] * T2[j >> 22]
 template <class Fr>
+__device__ __forceinline__ Fr pow_from_tables(const Fr* __restrict__ pw, u32 j, u32 logn) {
+    Fr g = fr_load(&pw[j & (POW_TABLE_SIZE - 1)]);
+    if (logn > POW_TABLE_BITS) g = Fr::mul(g, fr_load(&pw[POW_TABLE_SIZE + ((j >> POW_TABLE_BITS) & (POW_TABLE_SIZE - 1))]));
+    if (logn > 2 * POW_TABLE_BITS) g = Fr::mul(g, fr_load(&pw[2 * POW_TABLE_SIZE + (j >> (2 * POW_TABLE_BITS))]));
+    return g;
+}
+
+// ---- the pass kernel ----------------------------------------------------------------------------------
+// Per-stage twiddle tables: stage s (butterfly span 2^s) owns the 2^s contiguous entries
+//   tws[(2^s - 1) + j] = w_{2^(s+1)}^j,  j < 2^s        (gathered from the w_M^i table)
+// so the loads of neighbouring butterflies coalesce at every stage and the low stages stay cache-resident.
+template <class Fr>
+__global__ void k_stage_tables(Fr* __restrict__ tws, const Fr* __restrict__ tw, u32 log_table) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >> log_table) return;
+    u32 s = 31 - __clz((u32)(i + 1));
+    size_t j = i + 1 - ((size_t)1 << s);
+    fr_store(&tws[i], fr_load(&tw[j << (log_table - s - 1)]));
+}
+
+// One pass: butterfly stages [lo, lo+nst) of a 2^logn transform, in place, on an LDS tile of 2^nst rows x
+// 2^cols_bits contiguous elements (cols_bits <= lo); batched over blockIdx.y (vectors `stride_vec` apart).
+//   DIF (DIT == 0): stages run from high to low, butterfly (u, v) -> (u + v, (u - v) * w)
+//   DIT (DIT == 1): stages run from low to high, butterfly (u, v) -> (u + v*w, u - v*w)
+// Every thread carries FOUR elements through TWO stages in registers (a radix-4 step): half the LDS round
+// trips and barriers of a stage-by-stage loop, two independent butterflies in flight per lane, and the three
+// twiddles of a step are loaded before the data (their addresses do not depend on it).  An odd stage count
+// ends with one radix-2 step.  Measured on 3 x 2^21 (tools/ntt_bench.hip): 78 G butterflies/s against 66 for
+// the stage-by-stage kernel it replaced; 103 G/s once the HBM phases are hidden (field-multiply peak 136 G/s).
+// Fused epilogue of the LAST pass of a DIF chain ("/m and coset shift" of the witness map, no extra HBM
+// round trip): post & 1 -> multiply by `scale`; post & 2 -> multiply by g^bitrev(index) from the power
+// tables `pw` (POW_TABLE_SIZE entries per level).
+template <class Fr, int DIT>
 __global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_pass(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ tw, u32 logn, u32 log_table,
-           u32 lo, u32 nst, int dit, int post, Fr scale, const Fr* __restrict__ pw) {
+k_ntt_pass4(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ tws, u32 logn, u32 lo, u32 nst,
+            u32 cols_bits, int post, Fr scale, const Fr* __restrict__ pw) {
     extern __shared__ uint4 lds_raw[];
     Fr* lds = reinterpret_cast<Fr*>(lds_raw);
+    const u32 nthr = blockDim.x;
     Fr* vec = data + (size_t)blockIdx.y * stride_vec;
-    u32 cols_bits = lo < (u32)NTT_TILE_LOG_COLS ? lo : (u32)NTT_TILE_LOG_COLS;
-    u32 rows = 1u << nst, cols = 1u << cols_bits;
-    u32 tile_elems = rows << cols_bits;
-    u32 mid_bits = lo - cols_bits;
-    u32 t = blockIdx.x;
-    u32 mid = t & ((1u << mid_bits) - 1u);
-    u32 high = t >> mid_bits;
-    size_t base = ((size_t)high << (lo + nst)) | ((size_t)mid << cols_bits);
-    // load tile: element (r, c) lives at base | r << lo | c ; LDS index r * cols + c
-    for (u32 e = threadIdx.x; e < tile_elems; e += NTT_THREADS) {
+    const u32 cols = 1u << cols_bits;
+    const u32 tile_elems = 1u << (nst + cols_bits);
+    const u32 mid_bits = lo - cols_bits;
+    const u32 mid = blockIdx.x & ((1u << mid_bits) - 1u);
+    const size_t base = ((size_t)(blockIdx.x >> mid_bits) << (lo + nst)) | ((size_t)mid << cols_bits);
+    for (u32 e = threadIdx.x; e < tile_elems; e += nthr) {
         u32 r = e >> cols_bits, c = e & (cols - 1);
         lds[e] = fr_load(&vec[base | ((size_t)r << lo) | c]);
     }
     __syncthreads();
-    u32 half_count = tile_elems >> 1;
-    for (u32 st = 0; st < nst; st++) {
-        u32 ls = dit ? st : (nst - 1 - st);          // local stage (bit of r)
-        u32 s = lo + ls;                              // global stage
-        for (u32 bidx = threadIdx.x; bidx < half_count; bidx += NTT_THREADS) {
-            // butterfly index -> (r without bit ls, c)
-            u32 c = bidx & (cols - 1);
-            u32 rr = bidx >> cols_bits;
-            u32 r0 = ((rr >> ls) << (ls + 1)) | (rr & ((1u << ls) - 1u));
-            u32 r1 = r0 | (1u << ls);
-            u32 i0 = (r0 << cols_bits) | c, i1 = (r1 << cols_bits) | c;
-            size_t g0 = base | ((size_t)r0 << lo) | c;           // global index of the upper element
-            u32 j = (u32)(g0 & (((size_t)1 << s) - 1));
-            Fr w = fr_load(&tw[(size_t)j << (log_table - s - 1)]);   // issued first: longest latency
-            Fr u = lds[i0], v = lds[i1];
-            if (dit) {
-                v = Fr::mul(v, w);
-                lds[i0] = Fr::add(u, v);
-                lds[i1] = Fr::sub(u, v);
+    const u32 npair = nst >> 1;
+    for (u32 k = 0; k < npair; k++) {
+        const u32 l = DIT ? 2 * k : nst - 2 - 2 * k;          // stages lo+l and lo+l+1
+        const u32 s = lo + l;
+        const Fr* t_lo = tws + (((size_t)1 << s) - 1);         // stage s
+        const Fr* t_hi = tws + (((size_t)2 << s) - 1);         // stage s+1
+        for (u32 q = threadIdx.x; q < (tile_elems >> 2); q += nthr) {
+            u32 c = q & (cols - 1), rr = q >> cols_bits;
+            u32 r0 = ((rr >> l) << (l + 2)) | (rr & ((1u << l) - 1u));
+            u32 j = (u32)((base | ((size_t)r0 << lo) | c) & (((size_t)1 << s) - 1));
+            Fr wc = fr_load(&t_lo[j]);
+            Fr wa = fr_load(&t_hi[j]);
+            Fr wb = fr_load(&t_hi[j + (1u << s)]);
+            u32 i0 = (r0 << cols_bits) | c, st = 1u << (l + cols_bits);
+            Fr x0 = lds[i0], x1 = lds[i0 + st], x2 = lds[i0 + 2 * st], x3 = lds[i0 + 3 * st];
+            if (DIT) {
+                Fr v = Fr::mul(x1, wc), u = Fr::mul(x3, wc);
+                x1 = Fr::sub(x0, v); x0 = Fr::add(x0, v);
+                x3 = Fr::sub(x2, u); x2 = Fr::add(x2, u);
+                v = Fr::mul(x2, wa); u = Fr::mul(x3, wb);
+                x2 = Fr::sub(x0, v); x0 = Fr::add(x0, v);
+                x3 = Fr::sub(x1, u); x1 = Fr::add(x1, u);
             } else {
-                lds[i0] = Fr::add(u, v);
-                lds[i1] = Fr::mul(Fr::sub(u, v), w);
+                Fr v = Fr::sub(x0, x2), u = Fr::sub(x1, x3);
+                x0 = Fr::add(x0, x2); x1 = Fr::add(x1, x3);
+                x2 = Fr::mul(v, wa); x3 = Fr::mul(u, wb);
+                v = Fr::sub(x0, x1); u = Fr::sub(x2, x3);
+                x0 = Fr::add(x0, x1); x2 = Fr::add(x2, x3);
+                x1 = Fr::mul(v, wc); x3 = Fr::mul(u, wc);
+            }
+            lds[i0] = x0; lds[i0 + st] = x1; lds[i0 + 2 * st] = x2; lds[i0 + 3 * st] = x3;
+        }
+        __syncthreads();
+    }
+    if (nst & 1) {
+        const u32 l = DIT ? nst - 1 : 0;
+        const u32 s = lo + l;
+        const Fr* t_lo = tws + (((size_t)1 << s) - 1);
+        for (u32 q = threadIdx.x; q < (tile_elems >> 1); q += nthr) {
+            u32 c = q & (cols - 1), rr = q >> cols_bits;
+            u32 r0 = ((rr >> l) << (l + 1)) | (rr & ((1u << l) - 1u));
+            u32 j = (u32)((base | ((size_t)r0 << lo) | c) & (((size_t)1 << s) - 1));
+            Fr w = fr_load(&t_lo[j]);
+            u32 i0 = (r0 << cols_bits) | c, st = 1u << (l + cols_bits);
+            Fr x0 = lds[i0], x1 = lds[i0 + st];
+            if (DIT) {
+                Fr v = Fr::mul(x1, w);
+                lds[i0] = Fr::add(x0, v);
+                lds[i0 + st] = Fr::sub(x0, v);
+            } else {
+                lds[i0] = Fr::add(x0, x1);
+                lds[i0 + st] = Fr::mul(Fr::sub(x0, x1), w);
             }
         }
         __syncthreads();
     }
-    for (u32 e = threadIdx.x; e < tile_elems; e += NTT_THREADS) {
+    for (u32 e = threadIdx.x; e < tile_elems; e += nthr) {
         u32 r = e >> cols_bits, c = e & (cols - 1);
         size_t gi = base | ((size_t)r << lo) | c;
         Fr x = lds[e];
-        if (post) {
-            x = Fr::mul(x, scale);
-            if (post == 2) {
-                u32 j = logn ? (__brev((u32)gi) >> (32 - logn)) : 0u;
-                Fr g = fr_load(&pw[j & 1023]);
-                if (logn > 10) g = Fr::mul(g, fr_load(&pw[1024 + ((j >> 10) & 1023)]));
-                if (logn > 20) g = Fr::mul(g, fr_load(&pw[2048 + (j >> 20)]));
-                x = Fr::mul(x, g);
-            }
-        }
+        if (post & 1) x = Fr::mul(x, scale);
+        if (post & 2) x = Fr::mul(x, pow_from_tables(pw, logn ? (__brev((u32)gi) >> (32 - logn)) : 0u, logn));
         fr_store(&vec[gi], x);
     }
 }
 
 // x[pos] *= scale * g^(idx)  with idx = pos (natural) or bitrev(pos) (after a DIF pass chain).
-// pw: three 1024-entry tables of g^(j), g^(1024 j), g^(2^20 j); batched over blockIdx.y.
+// pw: three POW_TABLE_SIZE-entry tables of g^(j), g^(2^11 j), g^(2^22 j); batched over blockIdx.y.
 template <class Fr>
 __global__ void k_scale_pow(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ pw, Fr scale,
                             u32 logn, int bitrev_index, int use_pow) {
@@ -134,10 +181,7 @@ __global__ void k_scale_pow(Fr* __restrict__ data, size_t stride_vec, const Fr* 
     x = Fr::mul(x, scale);
     if (use_pow) {
         u32 j = bitrev_index ? (logn ? (__brev((u32)pos) >> (32 - logn)) : 0u) : (u32)pos;
-        Fr g = fr_load(&pw[j & 1023]);
-        if (logn > 10) g = Fr::mul(g, fr_load(&pw[1024 + ((j >> 10) & 1023)]));
-        if (logn > 20) g = Fr::mul(g, fr_load(&pw[2048 + (j >> 20)]));
-        x = Fr::mul(x, g);
+        x = Fr::mul(x, pow_from_tables(pw, j, logn));
     }
     fr_store(&vec[pos], x);
 }
@@ -182,15 +226,17 @@ __global__ void k_copy_inputs(Fr* __restrict__ a, const Fr* __restrict__ z, u32 
     if (j < n_inst) fr_store(&a[n_c + j], fr_load(&z[j]));
 }
 
-// ab[i] = (a[i]*b[i] - c[i]) * zinv
+// ab[i] = (a[i]*b[i] - c[i]*kc) * k.  With a, b, c the UNSCALED inverse transforms (each m times too large)
+// kc = m and k = zinv / m^3 give ((a/m)(b/m) - c/m) * zinv / m: the three "/m" of the inverse NTTs before
+// and the one after are paid here, once per element instead of once per element per vector.
 template <class Fr>
 __global__ void k_qap_combine(Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c,
-                              Fr zinv, size_t m) {
+                              Fr kc, Fr k, size_t m) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     Fr x = Fr::mul(fr_load(&a[i]), fr_load(&b[i]));
-    x = Fr::sub(x, fr_load(&c[i]));
-    fr_store(&a[i], Fr::mul(x, zinv));
+    x = Fr::sub(x, Fr::mul(fr_load(&c[i]), kc));
+    fr_store(&a[i], Fr::mul(x, k));
 }
 
 #endif  // __HIPCC__

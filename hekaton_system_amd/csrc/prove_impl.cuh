@@ -45,9 +45,10 @@ static Fr host_from_limbs(const u32* l) {
 struct NttTables {
     std::mutex mu;
     u32 log_table = 0;
-    void* tw_fwd = nullptr;      // w_M^i,  i < M/2
-    void* tw_inv = nullptr;      // w_M^-i
-    void* pw_g = nullptr;        // 3 x 1024 powers of F::GENERATOR
+    void* tw_fwd = nullptr;      // per-stage tables of w (k_stage_tables), 2^log_table - 1 entries; stage s always uses the
+                                 // 2^(s+1)-th roots, so every transform size <= 2^log_table shares them
+    void* tw_inv = nullptr;      // same for w^-1
+    void* pw_g = nullptr;        // 3 x POW_TABLE_SIZE powers of F::GENERATOR
     void* pw_ginv = nullptr;
     std::vector<void*> retired;  // superseded tables stay alive until the context dies
 };
@@ -80,32 +81,38 @@ struct NttHost {
         }
         Fr t = winv;
         for (u32 k = 0; k < L; k++) { sqi[k] = t; t = Fr::sqr(t); }
-        std::vector<Fr> gs(30), gis(30);
+        const u32 NG = 3 * POW_TABLE_BITS;
+        std::vector<Fr> gs(NG), gis(NG);
         Fr g = host_from_limbs<Fr>(C::GEN), gi = host_from_limbs<Fr>(C::GEN_INV);
-        for (u32 k = 0; k < 30; k++) { gs[k] = g; gis[k] = gi; g = Fr::sqr(g); gi = Fr::sqr(gi); }
-        Fr *d_sq = nullptr, *tf = nullptr, *ti = nullptr, *pg = nullptr, *pgi = nullptr;
-        size_t half = (size_t)1 << (L - 1);
-        HK_HIP(hipMalloc((void**)&d_sq, sizeof(Fr) * 124));
-        HK_HIP(hipMalloc((void**)&tf, sizeof(Fr) * half));
-        HK_HIP(hipMalloc((void**)&ti, sizeof(Fr) * half));
-        HK_HIP(hipMalloc((void**)&pg, sizeof(Fr) * 3072));
-        HK_HIP(hipMalloc((void**)&pgi, sizeof(Fr) * 3072));
+        for (u32 k = 0; k < NG; k++) { gs[k] = g; gis[k] = gi; g = Fr::sqr(g); gi = Fr::sqr(gi); }
+        Fr *d_sq = nullptr, *tmp = nullptr, *tf = nullptr, *ti = nullptr, *pg = nullptr, *pgi = nullptr;
+        size_t half = (size_t)1 << (L - 1), full = (size_t)1 << L;
+        HK_HIP(hipMalloc((void**)&d_sq, sizeof(Fr) * (64 + 2 * NG)));
+        HK_HIP(hipMalloc((void**)&tmp, sizeof(Fr) * half));
+        HK_HIP(hipMalloc((void**)&tf, sizeof(Fr) * full));
+        HK_HIP(hipMalloc((void**)&ti, sizeof(Fr) * full));
+        HK_HIP(hipMalloc((void**)&pg, sizeof(Fr) * 3 * POW_TABLE_SIZE));
+        HK_HIP(hipMalloc((void**)&pgi, sizeof(Fr) * 3 * POW_TABLE_SIZE));
         HK_HIP(hipMemcpy(d_sq, sq.data(), sizeof(Fr) * 32, hipMemcpyHostToDevice));
         HK_HIP(hipMemcpy(d_sq + 32, sqi.data(), sizeof(Fr) * 32, hipMemcpyHostToDevice));
-        HK_HIP(hipMemcpy(d_sq + 64, gs.data(), sizeof(Fr) * 30, hipMemcpyHostToDevice));
-        HK_HIP(hipMemcpy(d_sq + 94, gis.data(), sizeof(Fr) * 30, hipMemcpyHostToDevice));
-        u32 blocks = (u32)((half + 255) / 256);
-        hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, 0, tf, d_sq, (u32)half, L - 1);
-        hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, 0, ti, d_sq + 32, (u32)half, L - 1);
-        for (int lvl = 0; lvl < 3; lvl++) {
-            hipLaunchKernelGGL((k_pow_table<Fr>), dim3(4), dim3(256), 0, 0, pg + 1024 * lvl,
-                               d_sq + 64 + 10 * lvl, 1024u, 10u);
-            hipLaunchKernelGGL((k_pow_table<Fr>), dim3(4), dim3(256), 0, 0, pgi + 1024 * lvl,
-                               d_sq + 94 + 10 * lvl, 1024u, 10u);
+        HK_HIP(hipMemcpy(d_sq + 64, gs.data(), sizeof(Fr) * NG, hipMemcpyHostToDevice));
+        HK_HIP(hipMemcpy(d_sq + 64 + NG, gis.data(), sizeof(Fr) * NG, hipMemcpyHostToDevice));
+        u32 blocks = (u32)((half + 255) / 256), blocks_full = (u32)((full + 255) / 256);
+        // w_M^i for i < M/2 (scratch), regrouped into one contiguous table per butterfly stage
+        hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, 0, tmp, d_sq, (u32)half, L - 1);
+        hipLaunchKernelGGL((k_stage_tables<Fr>), dim3(blocks_full), dim3(256), 0, 0, tf, tmp, L);
+        hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, 0, tmp, d_sq + 32, (u32)half, L - 1);
+        hipLaunchKernelGGL((k_stage_tables<Fr>), dim3(blocks_full), dim3(256), 0, 0, ti, tmp, L);
+        for (u32 lvl = 0; lvl < 3; lvl++) {
+            hipLaunchKernelGGL((k_pow_table<Fr>), dim3(POW_TABLE_SIZE / 256), dim3(256), 0, 0, pg + POW_TABLE_SIZE * lvl,
+                               d_sq + 64 + POW_TABLE_BITS * lvl, (u32)POW_TABLE_SIZE, (u32)POW_TABLE_BITS);
+            hipLaunchKernelGGL((k_pow_table<Fr>), dim3(POW_TABLE_SIZE / 256), dim3(256), 0, 0, pgi + POW_TABLE_SIZE * lvl,
+                               d_sq + 64 + NG + POW_TABLE_BITS * lvl, (u32)POW_TABLE_SIZE, (u32)POW_TABLE_BITS);
         }
         HK_HIP(hipGetLastError());
         HK_HIP(hipDeviceSynchronize());
         HK_HIP(hipFree(d_sq));
+        HK_HIP(hipFree(tmp));
         for (void* p : {T->tw_fwd, T->tw_inv, T->pw_g, T->pw_ginv})
             if (p) T->retired.push_back(p);
         T->tw_fwd = tf; T->tw_inv = ti; T->pw_g = pg; T->pw_ginv = pgi;
@@ -125,35 +132,45 @@ struct NttHost {
     }
 
     // all butterfly stages of a size-2^logn transform, `batch` vectors `stride` elements apart.
-    // post/scale/pw: optional fused epilogue of the LAST pass (see k_ntt_pass).
-    static hk_status passes(hipStream_t s, Fr* data, size_t stride, u32 batch, u32 logn, const Fr* tw,
-                            u32 log_table, int dit, int post = 0, const Fr* scale = nullptr,
-                            const Fr* pw = nullptr) {
+    // tws: per-stage twiddle tables.  post/scale/pw: optional fused epilogue of the LAST pass (see k_ntt_pass4).
+    static hk_status passes(hipStream_t s, Fr* data, size_t stride, u32 batch, u32 logn, const Fr* tws, int dit,
+                            int post = 0, const Fr* scale = nullptr, const Fr* pw = nullptr) {
         if (logn == 0) return HK_OK;
-        // bottom pass takes up to 11 stages (tile = 2^11 contiguous elements), the rest split evenly
-        u32 bottom = logn < 11 ? logn : 11;
+        // bottom pass: the low min(logn, 11) stages on contiguous tiles; the rest in passes of at most
+        // `upper_max` stages whose tiles are 2^nst rows of 2^(11 - nst) contiguous elements
+        static const u32 upper_max = [] {
+            const char* e = getenv("HK_NTT_UPPER_MAX");
+            u32 v = e ? (u32)atoi(e) : 6u;      // 2^21: 11+5+5, 2^22: 11+6+5 (a single 10-stage upper pass with
+                                                // 64-B rows measured the same alone and less steady under load)
+            return v < 1 ? 1u : (v > 10 ? 10u : v);
+        }();
+        u32 bottom = logn < (u32)NTT_TILE_LOG ? logn : (u32)NTT_TILE_LOG;
         u32 rest = logn - bottom;
-        u32 npass = (rest + NTT_TILE_LOG_ROWS - 1) / NTT_TILE_LOG_ROWS;
-        struct P { u32 lo, nst; } ps[8];
+        u32 npass = (rest + upper_max - 1) / upper_max;
+        struct P { u32 lo, nst, cols_bits; } ps[34];
         int np = 0;
-        ps[np++] = {0, bottom};
+        ps[np++] = {0, bottom, 0};
         u32 lo = bottom;
         for (u32 i = 0; i < npass; i++) {
             u32 nst = (rest - (lo - bottom) + (npass - i) - 1) / (npass - i);
-            ps[np++] = {lo, nst};
+            ps[np++] = {lo, nst, (u32)NTT_TILE_LOG - nst};
             lo += nst;
         }
         Fr one = Fr::one();
         for (int k = 0; k < np; k++) {
             const P& p = dit ? ps[k] : ps[np - 1 - k];
-            u32 cols_bits = p.lo < (u32)NTT_TILE_LOG_COLS ? p.lo : (u32)NTT_TILE_LOG_COLS;
-            u32 tile_log = p.nst + cols_bits;
-            u32 tiles = 1u << (logn - tile_log);
+            u32 tile_log = p.nst + p.cols_bits;
+            dim3 grid(1u << (logn - tile_log), batch);
             size_t lds = sizeof(Fr) << tile_log;
             bool last = k == np - 1;
-            hipLaunchKernelGGL((k_ntt_pass<Fr>), dim3(tiles, batch), dim3(NTT_THREADS), lds, s, data, stride,
-                               tw, logn, log_table, p.lo, p.nst, dit, last ? post : 0,
-                               (last && post) ? *scale : one, pw);
+            int pp = last ? post : 0;
+            const Fr& sc = (pp & 1) ? *scale : one;
+            if (dit)
+                hipLaunchKernelGGL((k_ntt_pass4<Fr, 1>), grid, dim3(NTT_THREADS), lds, s, data, stride, tws, logn, p.lo,
+                                   p.nst, p.cols_bits, pp, sc, pw);
+            else
+                hipLaunchKernelGGL((k_ntt_pass4<Fr, 0>), grid, dim3(NTT_THREADS), lds, s, data, stride, tws, logn, p.lo,
+                                   p.nst, p.cols_bits, pp, sc, pw);
         }
         HK_HIP(hipGetLastError());
         return HK_OK;
@@ -196,13 +213,13 @@ hk_status Ops<C>::ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int 
     if (!inverse) {
         // coset FFT: coeff j *= g^j, then FFT (A.2).  DIF then un-permute.
         if (coset) HK_TRY(N::scale(s, d, n, 1, log_m, (const Fr*)T->pw_g, Fr::one(), 0, 1));
-        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_fwd, T->log_table, 0));
+        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_fwd, 0));
         HK_TRY(N::bitrev(s, d, log_m));
     } else {
         // iFFT: DIF with w^-1, scale by 1/m (and g^-j for the coset form), un-permute
         Fr minv = N::size_inv(log_m);
-        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0, coset ? 2 : 1, &minv,
-                         (const Fr*)T->pw_ginv));
+        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_inv, 0,
+                         coset ? 3 : 1, &minv, (const Fr*)T->pw_ginv));
         HK_TRY(N::bitrev(s, d, log_m));
     }
     if (!dev) HK_HIP(hipMemcpyAsync(data, d, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
@@ -238,15 +255,19 @@ struct QapHost {
         }
         hipLaunchKernelGGL((k_copy_inputs<Fr>), dim3((u32)((n_inst + 255) / 256)), dim3(256), 0, s, abc, z,
                            (u32)n_c, (u32)n_inst);
+        // ifft (DIF) with the "* g^j" coset shift fused into its last pass; the "/m" of every inverse
+        // transform is folded into k_qap_combine's constants
+        const Fr* tinv = (const Fr*)T->tw_inv;
+        const Fr* tfwd = (const Fr*)T->tw_fwd;
+        HK_TRY(N::passes(s, abc, m, 3, log_m, tinv, 0, 2, nullptr, (const Fr*)T->pw_g));
+        HK_TRY(N::passes(s, abc, m, 3, log_m, tfwd, 1));                                      // coset fft (DIT)
         Fr minv = N::size_inv(log_m);
-        // ifft (DIF) with the "/m, * g^j" coset shift fused into its last pass
-        HK_TRY(N::passes(s, abc, m, 3, log_m, (const Fr*)T->tw_inv, T->log_table, 0, 2, &minv, (const Fr*)T->pw_g));
-        HK_TRY(N::passes(s, abc, m, 3, log_m, (const Fr*)T->tw_fwd, T->log_table, 1));       // coset fft (DIT)
-        Fr zinv = N::vanishing_inv_on_coset(log_m);
+        Fr kc = fp_inv(minv);                                                                 // m
+        Fr k = Fr::mul(N::vanishing_inv_on_coset(log_m), Fr::mul(minv, Fr::mul(minv, minv)));  // zinv / m^3
         hipLaunchKernelGGL((k_qap_combine<Fr>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s, abc, abc + m,
-                           abc + 2 * m, zinv, m);
-        // coset ifft (DIF) with "/m, * g^-j" fused
-        HK_TRY(N::passes(s, abc, m, 1, log_m, (const Fr*)T->tw_inv, T->log_table, 0, 2, &minv, (const Fr*)T->pw_ginv));
+                           abc + 2 * m, kc, k, m);
+        // coset ifft (DIF) with "* g^-j" fused
+        HK_TRY(N::passes(s, abc, m, 1, log_m, tinv, 0, 2, nullptr, (const Fr*)T->pw_ginv));
         HK_HIP(hipGetLastError());
         return HK_OK;
     }
