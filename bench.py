@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--config", default="big-merkle-64x32",
                     help="workload (hekaton_system_amd/workload.py CONFIGS); default = BASELINE configs[1]")
     ap.add_argument("--curve", default="bn254", help="bn254 is what the reference instantiates (SURVEY F1)")
-    ap.add_argument("--subcircuits", type=int, default=8, help="subcircuits per GPU per step")
+    ap.add_argument("--subcircuits", type=int, default=64,
+                    help="subcircuits per GPU per step (default: the 64 subcircuits of BASELINE configs[1], "
+                         "big-merkle N=64; a step is that whole batch, proved 8 at a time)")
     ap.add_argument("--threads", type=int, default=8, help="host threads (= GPU lanes) proving concurrently")
     ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -82,16 +82,20 @@ __global__ void k_stage_tables(Fr* __restrict__ tws, const Fr* __restrict__ tw, 
 // twiddles of a step are loaded before the data (their addresses do not depend on it).  An odd stage count
 // ends with one radix-2 step.  Measured on 3 x 2^21 (tools/ntt_bench.hip): 78 G butterflies/s against 66 for
 // the stage-by-stage kernel it replaced; 103 G/s once the HBM phases are hidden (field-multiply peak 136 G/s).
-// Fused epilogue of the LAST pass of a DIF chain ("/m and coset shift" of the witness map, no extra HBM
-// round trip): post & 1 -> multiply by `scale`; post & 2 -> multiply by g^bitrev(index) from the power
-// tables `pw` (POW_TABLE_SIZE entries per level).
+// Fused epilogue of the LAST pass of a DIF chain (the coset shift / quotient step of the witness map, no
+// extra HBM round trip), applied to the vectors blockIdx.y < npost, in this order:
+//   post & 2 -> x *= g^bitrev(index)   (power tables `pw`, POW_TABLE_SIZE entries per level)
+//   post & 4 -> x -= sub[index] * kc   (`sub`: another vector in the same bit-reversed order)
+//   post & 1 -> x *= scale
 template <class Fr, int DIT>
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass4(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ tws, u32 logn, u32 lo, u32 nst,
-            u32 cols_bits, int post, Fr scale, const Fr* __restrict__ pw) {
+            u32 cols_bits, int post, u32 npost, Fr scale, const Fr* __restrict__ pw, const Fr* __restrict__ sub,
+            Fr kc) {
     extern __shared__ uint4 lds_raw[];
     Fr* lds = reinterpret_cast<Fr*>(lds_raw);
     const u32 nthr = blockDim.x;
+    if (blockIdx.y >= npost) post = 0;
     Fr* vec = data + (size_t)blockIdx.y * stride_vec;
     const u32 cols = 1u << cols_bits;
     const u32 tile_elems = 1u << (nst + cols_bits);
@@ -163,8 +167,9 @@ k_ntt_pass4(Fr* __restrict__ data, size_t stride_vec, const Fr* __restrict__ tws
         u32 r = e >> cols_bits, c = e & (cols - 1);
         size_t gi = base | ((size_t)r << lo) | c;
         Fr x = lds[e];
-        if (post & 1) x = Fr::mul(x, scale);
         if (post & 2) x = Fr::mul(x, pow_from_tables(pw, logn ? (__brev((u32)gi) >> (32 - logn)) : 0u, logn));
+        if (post & 4) x = Fr::sub(x, Fr::mul(fr_load(&sub[gi]), kc));
+        if (post & 1) x = Fr::mul(x, scale);
         fr_store(&vec[gi], x);
     }
 }
@@ -226,17 +231,13 @@ __global__ void k_copy_inputs(Fr* __restrict__ a, const Fr* __restrict__ z, u32 
     if (j < n_inst) fr_store(&a[n_c + j], fr_load(&z[j]));
 }
 
-// ab[i] = (a[i]*b[i] - c[i]*kc) * k.  With a, b, c the UNSCALED inverse transforms (each m times too large)
-// kc = m and k = zinv / m^3 give ((a/m)(b/m) - c/m) * zinv / m: the three "/m" of the inverse NTTs before
-// and the one after are paid here, once per element instead of once per element per vector.
+// a[i] *= b[i]   (the product of the coset evaluations; everything else of the quotient step is the epilogue
+// of the inverse transform that follows, see QapHost::run)
 template <class Fr>
-__global__ void k_qap_combine(Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c,
-                              Fr kc, Fr k, size_t m) {
+__global__ void k_mul_pointwise(Fr* __restrict__ a, const Fr* __restrict__ b, size_t m) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    Fr x = Fr::mul(fr_load(&a[i]), fr_load(&b[i]));
-    x = Fr::sub(x, Fr::mul(fr_load(&c[i]), kc));
-    fr_store(&a[i], Fr::mul(x, k));
+    fr_store(&a[i], Fr::mul(fr_load(&a[i]), fr_load(&b[i])));
 }
 
 #endif  // __HIPCC__

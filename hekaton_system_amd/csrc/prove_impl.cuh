@@ -131,10 +131,20 @@ struct NttHost {
         return fp_inv(Fr::sub(g, Fr::one()));
     }
 
+    // fused epilogue of the last pass (k_ntt_pass4): which steps, on how many of the batched vectors, operands
+    struct Post {
+        int post = 0;
+        u32 nvec = 0xffffffffu;
+        const Fr* scale = nullptr;    // post & 1
+        const Fr* pw = nullptr;       // post & 2
+        const Fr* sub = nullptr;      // post & 4
+        const Fr* kc = nullptr;
+    };
+
     // all butterfly stages of a size-2^logn transform, `batch` vectors `stride` elements apart.
-    // tws: per-stage twiddle tables.  post/scale/pw: optional fused epilogue of the LAST pass (see k_ntt_pass4).
+    // tws: per-stage twiddle tables.
     static hk_status passes(hipStream_t s, Fr* data, size_t stride, u32 batch, u32 logn, const Fr* tws, int dit,
-                            int post = 0, const Fr* scale = nullptr, const Fr* pw = nullptr) {
+                            const Post& ep = Post()) {
         if (logn == 0) return HK_OK;
         // bottom pass: the low min(logn, 11) stages on contiguous tiles; the rest in passes of at most
         // `upper_max` stages whose tiles are 2^nst rows of 2^(11 - nst) contiguous elements
@@ -163,14 +173,15 @@ struct NttHost {
             dim3 grid(1u << (logn - tile_log), batch);
             size_t lds = sizeof(Fr) << tile_log;
             bool last = k == np - 1;
-            int pp = last ? post : 0;
-            const Fr& sc = (pp & 1) ? *scale : one;
+            int pp = last ? ep.post : 0;
+            const Fr& sc = (pp & 1) ? *ep.scale : one;
+            const Fr& kc = (pp & 4) ? *ep.kc : one;
             if (dit)
                 hipLaunchKernelGGL((k_ntt_pass4<Fr, 1>), grid, dim3(NTT_THREADS), lds, s, data, stride, tws, logn, p.lo,
-                                   p.nst, p.cols_bits, pp, sc, pw);
+                                   p.nst, p.cols_bits, pp, ep.nvec, sc, ep.pw, ep.sub, kc);
             else
                 hipLaunchKernelGGL((k_ntt_pass4<Fr, 0>), grid, dim3(NTT_THREADS), lds, s, data, stride, tws, logn, p.lo,
-                                   p.nst, p.cols_bits, pp, sc, pw);
+                                   p.nst, p.cols_bits, pp, ep.nvec, sc, ep.pw, ep.sub, kc);
         }
         HK_HIP(hipGetLastError());
         return HK_OK;
@@ -218,8 +229,11 @@ hk_status Ops<C>::ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int 
     } else {
         // iFFT: DIF with w^-1, scale by 1/m (and g^-j for the coset form), un-permute
         Fr minv = N::size_inv(log_m);
-        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_inv, 0,
-                         coset ? 3 : 1, &minv, (const Fr*)T->pw_ginv));
+        typename N::Post ep;
+        ep.post = coset ? 3 : 1;
+        ep.scale = &minv;
+        ep.pw = (const Fr*)T->pw_ginv;
+        HK_TRY(N::passes(s, d, n, 1, log_m, (const Fr*)T->tw_inv, 0, ep));
         HK_TRY(N::bitrev(s, d, log_m));
     }
     if (!dev) HK_HIP(hipMemcpyAsync(data, d, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
@@ -255,19 +269,29 @@ struct QapHost {
         }
         hipLaunchKernelGGL((k_copy_inputs<Fr>), dim3((u32)((n_inst + 255) / 256)), dim3(256), 0, s, abc, z,
                            (u32)n_c, (u32)n_inst);
-        // ifft (DIF) with the "* g^j" coset shift fused into its last pass; the "/m" of every inverse
-        // transform is folded into k_qap_combine's constants
+        // With Z constant on the coset (Z(g w^i) = g^m - 1) and the transforms linear,
+        //     h = zinv * (coset_ifft(a_coset o b_coset) - ifft(c))
+        // which is bit for bit what A.1 computes with its seventh transform (c's coset fft) left out.
+        // Every inverse transform here is UNSCALED (m times too large); the powers of 1/m are folded into k, kc.
         const Fr* tinv = (const Fr*)T->tw_inv;
         const Fr* tfwd = (const Fr*)T->tw_fwd;
-        HK_TRY(N::passes(s, abc, m, 3, log_m, tinv, 0, 2, nullptr, (const Fr*)T->pw_g));
-        HK_TRY(N::passes(s, abc, m, 3, log_m, tfwd, 1));                                      // coset fft (DIT)
+        typename N::Post e1;                                   // ifft (DIF) of a, b, c; "* g^j" on a and b only
+        e1.post = 2;
+        e1.nvec = 2;
+        e1.pw = (const Fr*)T->pw_g;
+        HK_TRY(N::passes(s, abc, m, 3, log_m, tinv, 0, e1));
+        HK_TRY(N::passes(s, abc, m, 2, log_m, tfwd, 1));       // coset fft (DIT) of a, b
+        hipLaunchKernelGGL((k_mul_pointwise<Fr>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s, abc, abc + m, m);
         Fr minv = N::size_inv(log_m);
-        Fr kc = fp_inv(minv);                                                                 // m
-        Fr k = Fr::mul(N::vanishing_inv_on_coset(log_m), Fr::mul(minv, Fr::mul(minv, minv)));  // zinv / m^3
-        hipLaunchKernelGGL((k_qap_combine<Fr>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s, abc, abc + m,
-                           abc + 2 * m, kc, k, m);
-        // coset ifft (DIF) with "* g^-j" fused
-        HK_TRY(N::passes(s, abc, m, 1, log_m, tinv, 0, 2, nullptr, (const Fr*)T->pw_ginv));
+        Fr mm = fp_inv(Fr::mul(minv, minv));                                                    // m^2
+        Fr k = Fr::mul(N::vanishing_inv_on_coset(log_m), Fr::mul(minv, Fr::mul(minv, minv)));   // zinv / m^3
+        typename N::Post e2;                                   // coset ifft (DIF): (x * g^-j - c' * m^2) * zinv/m^3
+        e2.post = 2 | 4 | 1;
+        e2.pw = (const Fr*)T->pw_ginv;
+        e2.sub = abc + 2 * m;
+        e2.kc = &mm;
+        e2.scale = &k;
+        HK_TRY(N::passes(s, abc, m, 1, log_m, tinv, 0, e2));
         HK_HIP(hipGetLastError());
         return HK_OK;
     }

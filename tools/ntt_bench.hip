@@ -124,10 +124,10 @@ static void run_new(Fr* data, size_t stride, u32 batch, u32 logn, const Fr* tws,
         u32 tl = p.nst + p.cols_bits;
         if (dit)
             hipLaunchKernelGGL((k_ntt_pass4<Fr, 1>), dim3(1u << (logn - tl), batch), dim3(threads), sizeof(Fr) << tl, 0, data, stride, tws, logn,
-                               p.lo, p.nst, p.cols_bits, 0, one, (const Fr*)nullptr);
+                               p.lo, p.nst, p.cols_bits, 0, 0u, one, (const Fr*)nullptr, (const Fr*)nullptr, one);
         else
             hipLaunchKernelGGL((k_ntt_pass4<Fr, 0>), dim3(1u << (logn - tl), batch), dim3(threads), sizeof(Fr) << tl, 0, data, stride, tws, logn,
-                               p.lo, p.nst, p.cols_bits, 0, one, (const Fr*)nullptr);
+                               p.lo, p.nst, p.cols_bits, 0, 0u, one, (const Fr*)nullptr, (const Fr*)nullptr, one);
     }
 }
 
