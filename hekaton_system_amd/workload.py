@@ -8,9 +8,15 @@ one assignment per subcircuit.  `SyntheticSubcircuit` produces exactly that shap
 
   * n_inst = 4 instance variables (1, entry_chal, tr_chal, root — subcircuit_circuit.rs:174-179)
   * stage 0: n0 full-width witnesses (ROM entry = 2 witnesses, rom_transcript.rs:286-306)
-  * stage 1: free witnesses (85 % bits / 15 % full-width, SHA-like) and one product witness per
-    constraint; rows have 3 / 2 / 1 non-zeros in A / B / C with small coefficients, and the
-    assignment satisfies every row (so (ab - c)/Z is a polynomial and real proofs verify).
+  * stage 1: free witnesses (85 % bits / 15 % full-width) and one gate-output witness per constraint.
+    85 % of the constraints are boolean gates, as in a SHA-256 circuit — XOR `(2a)·(b) = a + b − p` and AND / NAND
+    `(a | 1−a)·(b | 1−b) = p | 1−p` — whose operands are drawn uniformly from ALL earlier boolean variables (free bits
+    and earlier gate outputs), so gate outputs stay bits (p(1) ≈ ½ through the XORs) at any depth; 15 % are
+    full-width rows `(3 terms)·(2 terms) = p` over ALL earlier variables.  Every assignment satisfies every
+    row, so (ab − c)/Z is a polynomial and real proofs verify.
+  * consequence for the proving key: the A / B queries are dense (≈ 70 % / ≈ 65 % non-infinity bases at the
+    2^21 size; printed by `query_density()`), and the assignment is the SURVEY §8d mixture: ≈ 85 % of the
+    scalars in {0, 1}, ≈ 15 % uniform in [0, r).
 """
 import numpy as np
 
@@ -29,7 +35,8 @@ CONFIGS = {
 
 class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
     N_INST = 4
-    BIT_COEFFS = [1, 1, 1, 2]
+    N_LAYERS = 16                     # rows of layer l only reference variables created before layer l
+    KIND_WIDE, KIND_XOR, KIND_AND = 0, 1, 2
 
     def __init__(self, curve, n_c, n_free, n0, class_seed=0x48454B41544F4E31, bit_fraction=0.85):
         self.curve = curve
@@ -43,15 +50,35 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
         ni = self.N_INST
         self.is_bit_var = rng.random(n_free) < bit_fraction
         self.is_bit_var[:n0] = False
-        bit_cols = ni + np.nonzero(self.is_bit_var)[0]
-        if len(bit_cols) == 0:
-            bit_cols = np.array([ni + n0], dtype=np.int64)
-        self.row_is_bit = rng.random(n_c) < bit_fraction
-        any_cols = rng.integers(0, ni + n_free, size=(n_c, 5))
-        pick = bit_cols[rng.integers(0, len(bit_cols), size=(n_c, 5))]
-        self.cols = np.where(self.row_is_bit[:, None], pick, any_cols).astype(np.int64)   # A: 0..2, B: 3..4
-        self.coef_idx = np.where(self.row_is_bit[:, None], rng.integers(0, 4, size=(n_c, 5)),
-                                 rng.integers(0, 8, size=(n_c, 5))).astype(np.int64)
+        if not self.is_bit_var.any():
+            self.is_bit_var[min(n0, n_free - 1)] = True
+        u = rng.random(n_c)
+        self.kind = np.where(u < 1.0 - bit_fraction, self.KIND_WIDE,
+                             np.where(u < 1.0 - bit_fraction + 0.6 * bit_fraction, self.KIND_XOR, self.KIND_AND)).astype(np.int8)
+        self.neg = (rng.random((n_c, 2)) < 0.25) & (self.kind == self.KIND_AND)[:, None]   # AND operands may be 1 - x
+        self.neg_out = (rng.random(n_c) < 0.5) & (self.kind == self.KIND_AND)               # NAND: a * b = 1 - p
+        self.cols = np.zeros((n_c, 5), dtype=np.int64)          # bit rows use cols[:, 0] (A) and cols[:, 3] (B)
+        self.coef_idx = rng.integers(0, 8, size=(n_c, 5)).astype(np.int64)                 # wide rows only
+        base = ni + n_free
+        self.layer_bounds = [n_c * l // self.N_LAYERS for l in range(self.N_LAYERS + 1)]
+        bit_pool = [ni + np.nonzero(self.is_bit_var)[0]]
+        wide_pool = [np.arange(1, ni), ni + np.nonzero(~self.is_bit_var)[0]]
+        for l in range(self.N_LAYERS):
+            lo, hi = self.layer_bounds[l], self.layer_bounds[l + 1]
+            if hi == lo:
+                continue
+            pool = np.concatenate(bit_pool)
+            rows = np.arange(lo, hi)
+            wide = self.kind[rows] == self.KIND_WIDE
+            n_avail = base + lo                                  # every variable created before this layer
+            pick_bits = pool[rng.integers(0, len(pool), size=(hi - lo, 5))]
+            pick_any = rng.integers(1, n_avail, size=(hi - lo, 5))
+            wpool = np.concatenate(wide_pool)
+            pick_wide = wpool[rng.integers(0, len(wpool), size=(hi - lo, 5))]
+            lead = np.array([True, False, False, True, False])   # first A and first B operand of a wide row are wide
+            self.cols[lo:hi] = np.where(wide[:, None], np.where(lead[None, :], pick_wide, pick_any), pick_bits)
+            bit_pool.append(base + rows[~wide])
+            wide_pool.append(base + rows[wide])
         self.seed = None
         self._z = None
 
@@ -81,21 +108,61 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
             cs.finalize_stage()
 
     # ---- static matrices ---------------------------------------------------------------------------
-    def _coef_int(self, i, k):
-        return self.BIT_COEFFS[self.coef_idx[i, k]] if self.row_is_bit[i] else self.wide_coeffs[self.coef_idx[i, k]]
+    def rows(self, i):
+        """Row i as ark `ConstraintMatrices` rows: ([(coeff, col)] for A, B, C), coefficients as ints mod r."""
+        r, k = self.r, int(self.kind[i])
+        co = self.cols[i].tolist()
+        p = self.N_INST + self.n_free + i
+        if k == self.KIND_WIDE:
+            wc, ci = self.wide_coeffs, self.coef_idx[i].tolist()
+            return ([(wc[ci[0]], co[0]), (wc[ci[1]], co[1]), (wc[ci[2]], co[2])],
+                    [(wc[ci[3]], co[3]), (wc[ci[4]], co[4])], [(1, p)])
+        x0, x1 = co[0], co[3]
+        if k == self.KIND_XOR:
+            return [(2, x0)], [(1, x1)], [(1, x0), (1, x1), (r - 1, p)]
+        a = [(1, 0), (r - 1, x0)] if self.neg[i, 0] else [(1, x0)]
+        b = [(1, 0), (r - 1, x1)] if self.neg[i, 1] else [(1, x1)]
+        return a, b, ([(1, 0), (r - 1, p)] if self.neg_out[i] else [(1, p)])
 
     def csr(self, fc):
-        n_c, ni = self.n_c, self.N_INST
-        bit_tab = fc.enc(self.BIT_COEFFS).reshape(4, fc.nb)
-        wide_tab = fc.enc(self.wide_coeffs).reshape(8, fc.nb)
-        vals = np.where(self.row_is_bit[:, None, None], bit_tab[self.coef_idx % 4], wide_tab[self.coef_idx])
-        A = (np.arange(n_c + 1, dtype=np.uint64) * 3, self.cols[:, :3].astype(np.uint32).ravel(),
-             np.ascontiguousarray(vals[:, :3]).ravel())
-        B = (np.arange(n_c + 1, dtype=np.uint64) * 2, self.cols[:, 3:].astype(np.uint32).ravel(),
-             np.ascontiguousarray(vals[:, 3:]).ravel())
-        one = fc.enc1(1)
-        C = (np.arange(n_c + 1, dtype=np.uint64), (ni + self.n_free + np.arange(n_c)).astype(np.uint32),
-             np.tile(one, n_c))
+        """The three matrices as (row_ptr u64, col u32, val Montgomery bytes) — built without a Python loop."""
+        n_c, ni, r = self.n_c, self.N_INST, self.r
+        kind, neg, cols = self.kind, self.neg, self.cols
+        p = (ni + self.n_free + np.arange(n_c)).astype(np.int64)
+        tab_vals = [1, 2, r - 1] + self.wide_coeffs               # value table: index 0: 1, 1: 2, 2: -1, 3..: wide
+        tab = fc.enc(tab_vals).reshape(len(tab_vals), fc.nb)
+        wide, xor, andk = kind == self.KIND_WIDE, kind == self.KIND_XOR, kind == self.KIND_AND
+
+        def build(cnt, entries):
+            """entries: list of (row mask, slot within the row, col array, value-table index array)"""
+            row_ptr = np.zeros(n_c + 1, dtype=np.uint64)
+            row_ptr[1:] = np.cumsum(cnt)
+            nnz = int(row_ptr[-1])
+            col = np.zeros(nnz, dtype=np.uint32)
+            vidx = np.zeros(nnz, dtype=np.int64)
+            start = row_ptr[:-1].astype(np.int64)
+            for mask, slot, c, v in entries:
+                pos = start[mask] + slot
+                col[pos] = c[mask] if isinstance(c, np.ndarray) else c
+                vidx[pos] = v[mask] if isinstance(v, np.ndarray) else v
+            return row_ptr, col, np.ascontiguousarray(tab[vidx]).ravel()
+
+        zero = np.zeros(n_c, dtype=np.int64)
+        n0m, n1m = andk & neg[:, 0], andk & neg[:, 1]
+        # A
+        cntA = np.where(wide, 3, np.where(n0m, 2, 1))
+        A = build(cntA, [(wide, 0, cols[:, 0], 3 + self.coef_idx[:, 0]), (wide, 1, cols[:, 1], 3 + self.coef_idx[:, 1]),
+                         (wide, 2, cols[:, 2], 3 + self.coef_idx[:, 2]),
+                         (xor, 0, cols[:, 0], 1), (andk & ~neg[:, 0], 0, cols[:, 0], 0),
+                         (n0m, 0, zero, 0), (n0m, 1, cols[:, 0], 2)])
+        cntB = np.where(wide, 2, np.where(n1m, 2, 1))
+        B = build(cntB, [(wide, 0, cols[:, 3], 3 + self.coef_idx[:, 3]), (wide, 1, cols[:, 4], 3 + self.coef_idx[:, 4]),
+                         (xor, 0, cols[:, 3], 0), (andk & ~neg[:, 1], 0, cols[:, 3], 0),
+                         (n1m, 0, zero, 0), (n1m, 1, cols[:, 3], 2)])
+        no = self.neg_out
+        cntC = np.where(xor, 3, np.where(no, 2, 1))
+        C = build(cntC, [(~xor & ~no, 0, p, 0), (no, 0, zero, 0), (no, 1, p, 2),
+                         (xor, 0, cols[:, 0], 0), (xor, 1, cols[:, 3], 0), (xor, 2, p, 2)])
         return A, B, C
 
     def qap_evaluate(self, t):
@@ -122,22 +189,64 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
             a[j] = u[n_c + j]
         cols = self.cols.tolist()
         cidx = self.coef_idx.tolist()
-        isbit = self.row_is_bit.tolist()
-        bc, wc = self.BIT_COEFFS, self.wide_coeffs
+        kind = self.kind.tolist()
+        neg = self.neg.tolist()
+        neg_out = self.neg_out.tolist()
+        wc = self.wide_coeffs
         base = ni + self.n_free
         for i in range(n_c):
-            ui = u[i]
-            tab = bc if isbit[i] else wc
-            ci, co = cidx[i], cols[i]
-            a[co[0]] += ui * tab[ci[0]]
-            a[co[1]] += ui * tab[ci[1]]
-            a[co[2]] += ui * tab[ci[2]]
-            b[co[3]] += ui * tab[ci[3]]
-            b[co[4]] += ui * tab[ci[4]]
-            c[base + i] = ui
+            ui, k, co = u[i], kind[i], cols[i]
+            if k == 1:                                   # XOR: (2 x0) * (x1) = x0 + x1 - p
+                a[co[0]] += 2 * ui
+                b[co[3]] += ui
+                c[co[0]] += ui
+                c[co[3]] += ui
+                c[base + i] -= ui
+            elif k == 2:                                 # AND with optional negations
+                if neg[i][0]:
+                    a[0] += ui
+                    a[co[0]] -= ui
+                else:
+                    a[co[0]] += ui
+                if neg[i][1]:
+                    b[0] += ui
+                    b[co[3]] -= ui
+                else:
+                    b[co[3]] += ui
+                if neg_out[i]:
+                    c[0] += ui
+                    c[base + i] -= ui
+                else:
+                    c[base + i] += ui
+            else:
+                ci = cidx[i]
+                a[co[0]] += ui * wc[ci[0]]
+                a[co[1]] += ui * wc[ci[1]]
+                a[co[2]] += ui * wc[ci[2]]
+                b[co[3]] += ui * wc[ci[3]]
+                b[co[4]] += ui * wc[ci[4]]
+                c[base + i] += ui
         a = [x % r for x in a]
         b = [x % r for x in b]
+        c = [x % r for x in c]
         return a, b, c, zt, m
+
+    def query_density(self):
+        """Fraction of variables with a non-zero column in A / in B (= non-infinity a_g / b_g, b_h bases, up to
+        the measure-zero event that a column's QAP evaluation vanishes at the setup point)."""
+        ina = np.zeros(self.n_v, dtype=bool)
+        inb = np.zeros(self.n_v, dtype=bool)
+        wide = self.kind == self.KIND_WIDE
+        ina[self.cols[:, 0]] = True
+        ina[self.cols[wide][:, 1:3].ravel()] = True
+        inb[self.cols[:, 3]] = True
+        inb[self.cols[wide][:, 4]] = True
+        if self.neg[:, 0].any():
+            ina[0] = True
+        if self.neg[:, 1].any():
+            inb[0] = True
+        ina[:self.N_INST] = True                         # a[j] = u[n_c + j] for the instance variables
+        return float(ina.mean()), float(inb.mean())
 
     # ---- per-subcircuit assignment ------------------------------------------------------------------
     def assignment_ints(self):
@@ -150,30 +259,39 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
         r, ni, n_free, n_c = self.r, self.N_INST, self.n_free, self.n_c
         rng = np.random.default_rng(self.seed)
         prng = random.Random(int(self.seed))
-        base = np.zeros(ni + n_free, dtype=np.int64)
-        base[ni:][self.is_bit_var] = rng.integers(0, 2, size=int(self.is_bit_var.sum()))
-        z = base.tolist()
+        bits = np.zeros(self.n_v, dtype=np.int64)              # value of every boolean variable (others unused)
+        free_bits = ni + np.nonzero(self.is_bit_var)[0]
+        bits[free_bits] = rng.integers(0, 2, size=len(free_bits))
+        z = [0] * self.n_v
         z[0] = 1
         for j in range(1, ni):
             z[j] = prng.randrange(r)
         for j in np.nonzero(~self.is_bit_var)[0].tolist():
             z[ni + j] = prng.randrange(r)
-        # bit rows, vectorised: small non-negative integers
-        bt = np.array(self.BIT_COEFFS, dtype=np.int64)
-        rows = np.nonzero(self.row_is_bit)[0]
-        v = base[self.cols[rows]] * bt[self.coef_idx[rows]]
-        prod = (v[:, 0] + v[:, 1] + v[:, 2]) * (v[:, 3] + v[:, 4])
-        w = [0] * n_c
-        for i, x in zip(rows.tolist(), prod.tolist()):
-            w[i] = x
+        for j, v in zip(free_bits.tolist(), bits[free_bits].tolist()):
+            z[j] = v
+        base = ni + n_free
         wc = self.wide_coeffs
-        cols, cidx = self.cols, self.coef_idx
-        for i in np.nonzero(~self.row_is_bit)[0].tolist():
-            co, ci = cols[i].tolist(), cidx[i].tolist()
-            az = z[co[0]] * wc[ci[0]] + z[co[1]] * wc[ci[1]] + z[co[2]] * wc[ci[2]]
-            bz = z[co[3]] * wc[ci[3]] + z[co[4]] * wc[ci[4]]
-            w[i] = az * bz % r
-        self._z = z + w
+        cols, cidx, kind, neg = self.cols, self.coef_idx, self.kind, self.neg
+        for l in range(self.N_LAYERS):
+            lo, hi = self.layer_bounds[l], self.layer_bounds[l + 1]
+            if hi == lo:
+                continue
+            k = kind[lo:hi]
+            x0, x1 = bits[cols[lo:hi, 0]], bits[cols[lo:hi, 3]]
+            av = np.where(neg[lo:hi, 0], 1 - x0, x0)
+            bv = np.where(neg[lo:hi, 1], 1 - x1, x1)
+            out = np.where(k == self.KIND_XOR, x0 ^ x1, np.where(self.neg_out[lo:hi], 1 - av * bv, av * bv))
+            bit_rows = np.nonzero(k != self.KIND_WIDE)[0]
+            bits[base + lo + bit_rows] = out[bit_rows]
+            for i, v in zip((base + lo + bit_rows).tolist(), out[bit_rows].tolist()):
+                z[i] = v
+            for i in (lo + np.nonzero(k == self.KIND_WIDE)[0]).tolist():
+                co, ci = cols[i].tolist(), cidx[i].tolist()
+                az = z[co[0]] * wc[ci[0]] + z[co[1]] * wc[ci[1]] + z[co[2]] * wc[ci[2]]
+                bz = z[co[3]] * wc[ci[3]] + z[co[4]] * wc[ci[4]]
+                z[base + i] = az * bz % r
+        self._z = z
         return self._z
 
     def full_assignment_bytes(self, cs=None):

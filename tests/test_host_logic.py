@@ -60,12 +60,20 @@ def test_synthetic_subcircuit_is_satisfiable_and_shaped():
     assert z[0] == 1 and len(z) == circ.n_v == 4 + CONFIGS["tiny"]["n_free"] + CONFIGS["tiny"]["n_c"]
     fc = FrCodec("bn254")
     (rpa, ca, va), (rpb, cb, vb), (rpc, cc, vc) = circ.csr(fc)
-    da, db = fc.dec(va), fc.dec(vb)
+    da, db, dc = fc.dec(va), fc.dec(vb), fc.dec(vc)
     r = circ.r
+    dot = lambda rp, col, d, i: sum(d[k] * z[col[k]] for k in range(int(rp[i]), int(rp[i + 1]))) % r
     for i in range(circ.n_c):
-        az = sum(da[k] * z[ca[k]] for k in range(int(rpa[i]), int(rpa[i + 1]))) % r
-        bz = sum(db[k] * z[cb[k]] for k in range(int(rpb[i]), int(rpb[i + 1]))) % r
-        assert az * bz % r == z[cc[i]]
+        assert dot(rpa, ca, da, i) * dot(rpb, cb, db, i) % r == dot(rpc, cc, dc, i)
+        ra, rb, rc = circ.rows(i)                                   # the per-row view agrees with the CSR
+        assert [(da[k], int(ca[k])) for k in range(int(rpa[i]), int(rpa[i + 1]))] == ra
+        assert [(db[k], int(cb[k])) for k in range(int(rpb[i]), int(rpb[i + 1]))] == rb
+        assert [(dc[k], int(cc[k])) for k in range(int(rpc[i]), int(rpc[i + 1]))] == rc
+    # SHA-like mixture and dense queries
+    small = sum(1 for x in z if x < 2) / len(z)
+    assert 0.75 < small < 0.95
+    da_, db_ = circ.query_density()
+    assert da_ > 0.3 and db_ > 0.3
     # stage split: 4 instance variables, n0 stage-0 witnesses first
     cs = MultiStageConstraintSystem(r, construct_matrices=False)
     circ.generate_constraints(0, cs)
