@@ -67,7 +67,7 @@ __device__ __forceinline__ Fr pow_from_tables(const Fr* __restrict__ pw, u32 j, 
 template <class Fr>
 __global__ void k_stage_tables(Fr* __restrict__ tws, const Fr* __restrict__ tw, u32 log_table) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i + 1 >> log_table) return;
+    if ((i + 1) >> log_table) return;
     u32 s = 31 - __clz((u32)(i + 1));
     size_t j = i + 1 - ((size_t)1 << s);
     fr_store(&tws[i], fr_load(&tw[j << (log_table - s - 1)]));

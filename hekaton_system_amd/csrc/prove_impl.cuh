@@ -348,6 +348,14 @@ struct PkImpl {
     Affine<Fq>* a_tab = nullptr;           // [F][n_ext]   a_g[1..] | delta_g | inf ...
     Affine<Fq>* b1_tab = nullptr;          // [F][n_ext]   b_g[1..] | inf | delta_g | inf ...
     Affine<Fq2>* b2_tab = nullptr;         // [F][n_ext]   b_h[1..] | inf | delta_h | inf ...
+    // B-query density (bellman's DensityTracker idea): b_g[i] and b_h[i] are infinity for every variable that
+    // never occurs in B.  When enough of them are, B1 and B2 run over the compacted list b_idx (ext indices of
+    // the non-infinity bases, then every ext slot) with their own digit sort; b1_tab / b2_tab then hold
+    // [F][b_n] entries and plan_b replaces plan_z for them.
+    bool b_compact = false;
+    u32 b_n = 0;
+    u32* b_idx = nullptr;
+    MsmPlan plan_b;
     Affine<Fq>* l_tab = nullptr;           // [F][l_n]     ck_last | inf | inf | -delta_g | -delta_i ...
     u32 l_n = 0, l_off = 0;
     bool has_qap = false;
@@ -392,6 +400,22 @@ __global__ void k_pk_bitrev_copy(Affine<F>* __restrict__ tab, const Affine<F>* _
     st_vec(&tab[r], p);
 }
 
+// flags[i] = 1 iff pts[i] is not the point at infinity
+template <class F>
+__global__ void k_mark_noninf(const Affine<F>* __restrict__ pts, u32* __restrict__ flags, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = ld_vec(&pts[i]).is_inf() ? 0u : 1u;
+}
+// dst[k] = src[idx[k]] for idx[k] < n_src (ext slots beyond the source stay as they are)
+template <class T>
+__global__ void k_gather(T* __restrict__ dst, const T* __restrict__ src, const u32* __restrict__ idx, u32 n,
+                         u32 n_src) {
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    u32 i = idx[k];
+    if (i < n_src) st_vec(&dst[k], ld_vec(&src[i]));
+}
+
 template <class C>
 hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
     typedef PkImpl<C> PK;
@@ -428,27 +452,73 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
     Affine<Fq> inf1 = Affine<Fq>::inf();
     // --- A / B1 / B2 tables
     hk_status st;
-    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->a_tab)) != HK_OK) return fail(st);
-    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->b1_tab)) != HK_OK) return fail(st);
-    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->b2_tab)) != HK_OK) return fail(st);
-    HK_HIP(hipMemset(pk->a_tab, 0, g1 * pk->n_ext));
-    HK_HIP(hipMemset(pk->b1_tab, 0, g1 * pk->n_ext));
-    HK_HIP(hipMemset(pk->b2_tab, 0, g2 * pk->n_ext));
     const char* a_g = (const char*)d->a_g; const char* b_g = (const char*)d->b_g; const char* b_h = (const char*)d->b_h;
     const char* deltas = (const char*)d->deltas_g;
     const char* delta_last_g = deltas + g1 * k;
-    if (nq) {
-        HK_HIP(hipMemcpy(pk->a_tab, a_g + g1, g1 * nq, h2d_kind(a_g)));
-        HK_HIP(hipMemcpy(pk->b1_tab, b_g + g1, g1 * nq, h2d_kind(b_g)));
-        HK_HIP(hipMemcpy(pk->b2_tab, b_h + g2, g2 * nq, h2d_kind(b_h)));
-    }
-    HK_HIP(hipMemcpy(pk->a_tab + nq + 0, delta_last_g, g1, h2d_kind(deltas)));          // r * delta_g
-    HK_HIP(hipMemcpy(pk->b1_tab + nq + 1, delta_last_g, g1, h2d_kind(deltas)));         // s * delta_g
-    HK_HIP(hipMemcpy(pk->b2_tab + nq + 1, d->last_delta_h, g2, h2d_kind(d->last_delta_h)));   // s * delta_h
     u32 shift = pz.c * pz.WP;
+    if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->a_tab)) != HK_OK) return fail(st);
+    HK_HIP(hipMemset(pk->a_tab, 0, g1 * pk->n_ext));
+    if (nq) HK_HIP(hipMemcpy(pk->a_tab, a_g + g1, g1 * nq, h2d_kind(a_g)));
+    HK_HIP(hipMemcpy(pk->a_tab + nq + 0, delta_last_g, g1, h2d_kind(deltas)));          // r * delta_g
     HK_TRY(MsmRun<Fq>::build_tables(s0, pk->a_tab, pk->n_ext, pz.F, shift));
-    HK_TRY(MsmRun<Fq>::build_tables(s0, pk->b1_tab, pk->n_ext, pz.F, shift));
-    HK_TRY(MsmRun<Fq2>::build_tables(s0, pk->b2_tab, pk->n_ext, pz.F, shift));
+    {
+        // B-query: full-size staging copies on the device, then either used as the tables' first group
+        // or compacted to the non-infinity bases
+        Affine<Fq>* sb1 = nullptr; Affine<Fq2>* sb2 = nullptr; u32* flags = nullptr;
+        std::vector<void*> tmp;
+        auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); tmp.clear(); };
+        auto tfail = [&](hk_status e) { cleanup(); return fail(e); };
+        auto talloc = [&](void** q, size_t b) { if (hipMalloc(q, b ? b : 16) != hipSuccess) { (void)hipGetLastError(); return false; } tmp.push_back(*q); return true; };
+        if (!talloc((void**)&sb1, g1 * (nq + 1)) || !talloc((void**)&sb2, g2 * (nq + 1)) || !talloc((void**)&flags, 4 * (nq + 1)))
+            return tfail(HK_ERR_NOMEM);
+        std::vector<u32> idx;
+        if (nq) {
+            if (hipMemcpy(sb1, b_g + g1, g1 * nq, h2d_kind(b_g)) != hipSuccess) return tfail(HK_ERR_DEVICE);
+            if (hipMemcpy(sb2, b_h + g2, g2 * nq, h2d_kind(b_h)) != hipSuccess) return tfail(HK_ERR_DEVICE);
+            hipLaunchKernelGGL((k_mark_noninf<Fq>), dim3((u32)((nq + 255) / 256)), dim3(256), 0, s0, sb1, flags, (u32)nq);
+            std::vector<u32> hf(nq);
+            if (hipMemcpy(hf.data(), flags, 4 * nq, hipMemcpyDeviceToHost) != hipSuccess) return tfail(HK_ERR_DEVICE);
+            for (size_t i = 0; i < nq; i++) if (hf[i]) idx.push_back((u32)i);
+        }
+        static const char* dens_env = getenv("HK_B_COMPACT_BELOW");     // density threshold in percent; 0 disables
+        double thr = dens_env ? atof(dens_env) / 100.0 : 0.75;
+        pk->b_compact = nq >= 4096 && (double)idx.size() < thr * (double)nq;
+        if (pk->b_compact) {
+            for (u32 e = 0; e < pk->n_extra; e++) idx.push_back((u32)nq + e);
+            pk->b_n = (u32)idx.size();
+            pk->plan_b = make_plan(pk->b_n);
+            void* di = nullptr;
+            if (hipMalloc(&di, 4 * (size_t)pk->b_n) != hipSuccess) { (void)hipGetLastError(); return tfail(HK_ERR_NOMEM); }
+            pk->owned.push_back(di);
+            pk->b_idx = (u32*)di;
+            pk->bytes += 4 * (size_t)pk->b_n;
+            if (hipMemcpy(di, idx.data(), 4 * (size_t)pk->b_n, hipMemcpyHostToDevice) != hipSuccess) return tfail(HK_ERR_DEVICE);
+        } else {
+            pk->b_n = pk->n_ext;
+            pk->plan_b = pz;
+        }
+        const MsmPlan& pb = pk->plan_b;
+        if ((st = pk_alloc_table(pk->owned, pk->bytes, pb.F, pk->b_n, &pk->b1_tab)) != HK_OK) return tfail(st);
+        if ((st = pk_alloc_table(pk->owned, pk->bytes, pb.F, pk->b_n, &pk->b2_tab)) != HK_OK) return tfail(st);
+        if (hipMemset(pk->b1_tab, 0, g1 * pk->b_n) != hipSuccess || hipMemset(pk->b2_tab, 0, g2 * pk->b_n) != hipSuccess)
+            return tfail(HK_ERR_DEVICE);
+        if (pk->b_compact) {
+            u32 blocks = (pk->b_n + 255) / 256;
+            hipLaunchKernelGGL((k_gather<Affine<Fq>>), dim3(blocks), dim3(256), 0, s0, pk->b1_tab, (const Affine<Fq>*)sb1, pk->b_idx, pk->b_n, (u32)nq);
+            hipLaunchKernelGGL((k_gather<Affine<Fq2>>), dim3(blocks), dim3(256), 0, s0, pk->b2_tab, (const Affine<Fq2>*)sb2, pk->b_idx, pk->b_n, (u32)nq);
+        } else if (nq) {
+            if (hipMemcpy(pk->b1_tab, sb1, g1 * nq, hipMemcpyDeviceToDevice) != hipSuccess) return tfail(HK_ERR_DEVICE);
+            if (hipMemcpy(pk->b2_tab, sb2, g2 * nq, hipMemcpyDeviceToDevice) != hipSuccess) return tfail(HK_ERR_DEVICE);
+        }
+        u32 s_slot = pk->b_n - pk->n_extra + 1;                                              // ext slot of s
+        if (hipMemcpy(pk->b1_tab + s_slot, delta_last_g, g1, h2d_kind(deltas)) != hipSuccess) return tfail(HK_ERR_DEVICE);     // s * delta_g
+        if (hipMemcpy(pk->b2_tab + s_slot, d->last_delta_h, g2, h2d_kind(d->last_delta_h)) != hipSuccess) return tfail(HK_ERR_DEVICE);   // s * delta_h
+        if (hipDeviceSynchronize() != hipSuccess) return tfail(HK_ERR_DEVICE);
+        cleanup();
+        u32 shift_b = pb.c * pb.WP;
+        HK_TRY(MsmRun<Fq>::build_tables(s0, pk->b1_tab, pk->b_n, pb.F, shift_b));
+        HK_TRY(MsmRun<Fq2>::build_tables(s0, pk->b2_tab, pk->b_n, pb.F, shift_b));
+    }
     // --- L table: last-stage committer key, then the negated deltas that fold -rs*delta and -kappa_i*delta_i
     size_t n1 = d->ck_len[k];
     pk->l_n = (u32)n1 + pk->n_extra;
@@ -769,9 +839,11 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     if (!L) return HK_ERR_DEVICE;
     const MsmPlan &pz = pk->plan_z, &ph = pk->plan_h;
     size_t m = (size_t)1 << pk->log_m;
+    const MsmPlan& pb = pk->plan_b;
     size_t need = al256(sizeof(Fr) * pk->n_ext) + al256(sizeof(Fr) * n_v) + msm_sort_bytes(pz) +
-                  msm_sort_bytes(ph) + 3 * msm_run_bytes<Fq>(pz) + msm_run_bytes<Fq>(ph) +
-                  msm_run_bytes<Fq2>(pz) + al256(3 * m * sizeof(Fr)) + 16384;
+                  msm_sort_bytes(ph) + 2 * msm_run_bytes<Fq>(pz) + msm_run_bytes<Fq>(pb) + msm_run_bytes<Fq>(ph) +
+                  msm_run_bytes<Fq2>(pb) + al256(3 * m * sizeof(Fr)) + 16384;
+    if (pk->b_compact) need += msm_sort_bytes(pb) + al256(sizeof(Fr) * pk->b_n);
     HK_TRY(L->reserve(need));
     hipStream_t s = L->stream;
     bool prof = ctx->profiling;
@@ -797,16 +869,22 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     if (n_kappas) HK_HIP(hipMemcpyAsync(small + 2, kappas, n_kappas * sizeof(Fr), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL((k_prep_ext<Fr>), dim3(1), dim3(64), 0, s, zext + (n_v - 1), small, (u32)n_kappas);
     // --- one digit sort shared by the four assignment-indexed queries
-    SortBufs sb, sbh;
+    SortBufs sb, sbh, sbb;
     HK_TRY(MsmSort<Fr>::alloc(L, pz, &sb));
     HK_TRY(MsmSort<Fr>::alloc(L, ph, &sbh));
+    Fr* zb = nullptr;
+    if (pk->b_compact) {
+        HK_TRY(MsmSort<Fr>::alloc(L, pb, &sbb));
+        zb = L->alloc_n<Fr>(pk->b_n);
+        if (!zb) return HK_ERR_NOMEM;
+    }
     typename MsmRun<Fq>::Bufs rbA, rbB1, rbL, rbh;
     typename MsmRun<Fq2>::Bufs rb2;
     HK_TRY(MsmRun<Fq>::alloc(L, pz, &rbA));
-    HK_TRY(MsmRun<Fq>::alloc(L, pz, &rbB1));
+    HK_TRY(MsmRun<Fq>::alloc(L, pb, &rbB1));
     HK_TRY(MsmRun<Fq>::alloc(L, pz, &rbL));
     HK_TRY(MsmRun<Fq>::alloc(L, ph, &rbh));
-    HK_TRY(MsmRun<Fq2>::alloc(L, pz, &rb2));
+    HK_TRY(MsmRun<Fq2>::alloc(L, pb, &rb2));
     XYZZ<Fq>* res1 = L->alloc_n<XYZZ<Fq>>(4);
     XYZZ<Fq2>* res2 = L->alloc_n<XYZZ<Fq2>>(1);
     Affine<Fq>* oa = L->alloc_n<Affine<Fq>>(2);
@@ -835,10 +913,24 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     HK_TRY(MsmSort<Fr>::run(s, pz, (const u32*)zext, 1, sb));
     HK_HIP(hipEventRecord(ev_sorted, s));
     HK_TRY(mark());                                                            // ev1: digits done
-    for (int k = 0; k < 3; k++) HK_HIP(hipStreamWaitEvent(ax[k], ev_sorted, 0));
-    HK_TRY(MsmRun<Fq2>::run(ax[1], pz, pk->b2_tab, pk->n_ext, 0, sb, rb2, res2, nullptr, nullptr));
+    HK_HIP(hipStreamWaitEvent(ax[2], ev_sorted, 0));
+    const SortBufs* sbB = &sb;
+    if (pk->b_compact) {
+        // B1 / B2 over the non-infinity bases only: gather their scalars, sort those digits on aux0
+        HK_HIP(hipStreamWaitEvent(ax[0], ev_z, 0));
+        hipLaunchKernelGGL((k_gather<Fr>), dim3((pk->b_n + 255) / 256), dim3(256), 0, ax[0], zb, (const Fr*)zext,
+                           (const u32*)pk->b_idx, pk->b_n, pk->n_ext);
+        HK_TRY(MsmSort<Fr>::run(ax[0], pb, (const u32*)zb, 1, sbb));
+        HK_HIP(hipEventRecord(ev[28], ax[0]));
+        HK_HIP(hipStreamWaitEvent(ax[1], ev[28], 0));
+        sbB = &sbb;
+    } else {
+        HK_HIP(hipStreamWaitEvent(ax[0], ev_sorted, 0));
+        HK_HIP(hipStreamWaitEvent(ax[1], ev_sorted, 0));
+    }
+    HK_TRY(MsmRun<Fq2>::run(ax[1], pb, pk->b2_tab, pk->b_n, 0, *sbB, rb2, res2, nullptr, nullptr));
     HK_HIP(hipEventRecord(ev[4], ax[1]));                                      // B2 done
-    HK_TRY(MsmRun<Fq>::run(ax[0], pz, pk->b1_tab, pk->n_ext, 0, sb, rbB1, res1 + 1, prof ? ev[22] : nullptr,
+    HK_TRY(MsmRun<Fq>::run(ax[0], pb, pk->b1_tab, pk->b_n, 0, *sbB, rbB1, res1 + 1, prof ? ev[22] : nullptr,
                            prof ? ev[23] : nullptr));
     HK_HIP(hipEventRecord(ev[3], ax[0]));                                      // B1 done
     HK_TRY(MsmRun<Fq>::run(ax[2], pz, pk->l_tab, pk->l_n, pk->l_off, sb, rbL, res1 + 2, prof ? ev[24] : nullptr,
