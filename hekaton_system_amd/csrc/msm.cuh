@@ -450,7 +450,8 @@ k_msm_build_tables(Affine<F>* __restrict__ table, u32 n, u32 F_groups, u32 shift
 // (re)derive the accumulate schedule of a plan for a kernel flavour that keeps `max_lanes0` lanes resident
 // (lanes = waves/SIMD the kernel is compiled for x 1024 SIMDs x 64): one full round of equal slices
 inline void msm_set_lanes(MsmPlan& p, u32 max_lanes0) {
-    p.Lmin0 = 32;
+    static const u32 lmin_env = [] { const char* e = getenv("HK_MSM_LMIN0"); return e && atoi(e) > 0 ? (u32)atoi(e) : 32u; }();
+    p.Lmin0 = lmin_env;
     u64 emax = (u64)p.n * p.W;
     u64 t0 = (emax + p.Lmin0 - 1) / p.Lmin0;
     if (t0 > max_lanes0) t0 = max_lanes0;
