@@ -132,6 +132,12 @@ struct Fp {
         return r;
     }
     HK_HD static Fp add(const Fp& a, const Fp& b) {
+#if defined(HK_USE_ASM_MUL)
+        // lazy fields: carry chain in VCC, 3N VALU instructions (gen_mont_asm.py gen_addsub)
+        if constexpr (P::LAZY && P::ASM_ID == 1) { Fp r; HK_ADD_ASM_BN254_FR(r, a, b); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 2) { Fp r; HK_ADD_ASM_BN254_FQ(r, a, b); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 4) { Fp r; HK_ADD_ASM_BLS12_381_FQ(r, a, b); return r; }
+#endif
         Fp t;
         u64 c = 0;
         HK_UNROLL for (int i = 0; i < N; i++) {
@@ -142,9 +148,21 @@ struct Fp {
         if constexpr (P::LAZY) return reduce_once_2p(t);   // a + b < 4*MOD
         return reduce_once(t);   // a + b < 2*MOD < 2^(32N)
     }
-    HK_HD static Fp dbl(const Fp& a) { return add(a, a); }
+    HK_HD static Fp dbl(const Fp& a) {
+#if defined(HK_USE_ASM_MUL)
+        if constexpr (P::LAZY && P::ASM_ID == 1) { Fp r; HK_DBL_ASM_BN254_FR(r, a); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 2) { Fp r; HK_DBL_ASM_BN254_FQ(r, a); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 4) { Fp r; HK_DBL_ASM_BLS12_381_FQ(r, a); return r; }
+#endif
+        return add(a, a);
+    }
 
     HK_HD static Fp sub(const Fp& a, const Fp& b) {
+#if defined(HK_USE_ASM_MUL)
+        if constexpr (P::LAZY && P::ASM_ID == 1) { Fp r; HK_SUB_ASM_BN254_FR(r, a, b); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 2) { Fp r; HK_SUB_ASM_BN254_FQ(r, a, b); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 4) { Fp r; HK_SUB_ASM_BLS12_381_FQ(r, a, b); return r; }
+#endif
         Fp t;
         u64 borrow = 0;
         HK_UNROLL for (int i = 0; i < N; i++) {

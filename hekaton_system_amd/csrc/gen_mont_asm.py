@@ -22,6 +22,30 @@ ACC = "v[4:5]"
 SBASE = 64                                   # s64.. hold the modulus limbs, then -p^-1
 
 
+def _column_ops(L):
+    """mac / shift emitters for the 96-bit column accumulator.  No register is ever cleared: the very first
+    product uses the constant 0 as its 64-bit addend, and the first carry of every column WRITES the third word
+    (v_addc 0 + 0 + carry) instead of adding into a word that a v_mov would have had to zero."""
+    state = {"first_ever": True, "first_in_column": True}
+
+    def mac(x, y):
+        addend = "0" if state["first_ever"] else ACC
+        L.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, addend))
+        if state["first_in_column"]:
+            L.append("v_addc_co_u32 %s, vcc, 0, 0, vcc" % ACC2)
+        else:
+            L.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (ACC2, ACC2))
+        state["first_ever"] = False
+        state["first_in_column"] = False
+
+    def shift():
+        L.append("v_mov_b32 %s, %s" % (ACC_LO, ACC_HI))
+        L.append("v_mov_b32 %s, %s" % (ACC_HI, ACC2))
+        state["first_in_column"] = True
+
+    return mac, shift
+
+
 def gen_block(name, p, n):
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
     limbs = [(p >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
@@ -35,18 +59,7 @@ def gen_block(name, p, n):
     for i, l in enumerate(limbs):
         L.append("s_mov_b32 %s, 0x%08x" % (P(i), l))
     L.append("s_mov_b32 %s, 0x%08x" % (SINV, inv))
-    L.append("v_mov_b32 %s, 0" % ACC_LO)
-    L.append("v_mov_b32 %s, 0" % ACC_HI)
-    L.append("v_mov_b32 %s, 0" % ACC2)
-
-    def mac(x, y):
-        L.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, ACC))
-        L.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (ACC2, ACC2))
-
-    def shift():
-        L.append("v_mov_b32 %s, %s" % (ACC_LO, ACC_HI))
-        L.append("v_mov_b32 %s, %s" % (ACC_HI, ACC2))
-        L.append("v_mov_b32 %s, 0" % ACC2)
+    mac, shift = _column_ops(L)
 
     for i in range(n):
         for j in range(i):
@@ -101,17 +114,7 @@ def gen_block_tied(name, p, n):
     for i, l in enumerate(limbs):
         L.append("s_mov_b32 %s, 0x%08x" % (P(i), l))
     L.append("s_mov_b32 %s, 0x%08x" % (SINV, inv))
-    for r in (ACC_LO, ACC_HI, ACC2):
-        L.append("v_mov_b32 %s, 0" % r)
-
-    def mac(x, y):
-        L.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, ACC))
-        L.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (ACC2, ACC2))
-
-    def shift():
-        L.append("v_mov_b32 %s, %s" % (ACC_LO, ACC_HI))
-        L.append("v_mov_b32 %s, %s" % (ACC_HI, ACC2))
-        L.append("v_mov_b32 %s, 0" % ACC2)
+    mac, shift = _column_ops(L)
 
     for i in range(n):
         for j in range(i):
@@ -149,6 +152,85 @@ def gen_block_tied(name, p, n):
 """ % dict(name=name, decl=decl, body=body, outs=outs, ins=ins, clob=clob, store=store), len(L)
 
 
+S_BASE_V = 8                                  # v8.. scratch for the trial subtraction of the lazy add
+
+
+def gen_addsub(name, p, n):
+    """Lazy-form ([0, 2p) in, [0, 2p) out) modular add / sub / double with the carry chain in VCC:
+    3n VALU instructions each, against ~6n for what hipcc makes of the portable u64 loops."""
+    R = 1 << (32 * n)
+    assert 4 * p <= R
+    p2 = [((2 * p) >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+    T = lambda i: "%%%d" % i                  # "+v": a_i in, result out
+    B = lambda i: "%%%d" % (n + i)
+    P = lambda i: "s%d" % (SBASE + i)
+    S = lambda i: "v%d" % (S_BASE_V + i)
+    ld = ["s_mov_b32 %s, 0x%08x" % (P(i), l) for i, l in enumerate(p2)]
+    sclob = ["s%d" % (SBASE + i) for i in range(n)]
+
+    def trial_sub(L):                         # r = t - 2p if that does not borrow, else t
+        # a carry-chain instruction may read only one scalar operand and VCC is one, so the 2p limbs go through
+        # the scratch VGPRs first (v_mov literal), then are overwritten by the difference
+        for i in range(n):
+            L.append("v_mov_b32 %s, 0x%08x" % (S(i), p2[i]))
+        L.append("v_sub_co_u32 %s, vcc, %s, %s" % (S(0), T(0), S(0)))
+        for i in range(1, n):
+            L.append("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (S(i), T(i), S(i)))
+        for i in range(n):
+            L.append("v_cndmask_b32 %s, %s, %s, vcc" % (T(i), S(i), T(i)))
+
+    add = []
+    add.append("v_add_co_u32 %s, vcc, %s, %s" % (T(0), T(0), B(0)))
+    for i in range(1, n):
+        add.append("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (T(i), T(i), B(i)))
+    trial_sub(add)
+    dbl = []
+    dbl.append("v_add_co_u32 %s, vcc, %s, %s" % (T(0), T(0), T(0)))
+    for i in range(1, n):
+        dbl.append("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (T(i), T(i), T(i)))
+    trial_sub(dbl)
+    sub = list(ld)
+    sub.append("v_sub_co_u32 %s, vcc, %s, %s" % (T(0), T(0), B(0)))
+    for i in range(1, n):
+        sub.append("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (T(i), T(i), B(i)))
+    sub.append("v_cndmask_b32 %s, 0, -1, vcc" % ACC_LO)                     # all ones iff the chain borrowed
+    for i in range(n):
+        sub.append("v_and_b32 %s, %s, %s" % (ACC_HI, P(i), ACC_LO))
+        if i == 0:
+            sub.append("v_add_co_u32 %s, vcc, %s, %s" % (T(0), T(0), ACC_HI))
+        else:
+            sub.append("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (T(i), T(i), ACC_HI))
+    decl = "    u32 " + ", ".join("t%d = a.v[%d]" % (i, i) for i in range(n)) + ";"
+    store = " ".join("r.v[%d] = t%d;" % (i, i) for i in range(n))
+    outs = ", ".join('"+&v"(t%d)' % i for i in range(n))
+    ins = ", ".join('"v"(b.v[%d])' % i for i in range(n))
+
+    def macro(kind, L, has_b, clob_v):
+        nonlocal sclob
+        clob = ", ".join('"%s"' % c for c in ["vcc"] + clob_v + sclob)
+        return """
+// %(name)s: r = a %(kind)s mod p on [0, 2p) representatives
+#define HK_%(KIND)s_ASM_%(name)s(r, a%(bparam)s)                                          \\
+    do {                                                                                 \\
+    %(decl)s                                                                             \\
+        asm("%(body)s"                                                                   \\
+            : %(outs)s                                                                   \\
+            : %(ins)s                                                                    \\
+            : %(clob)s);                                                                 \\
+        %(store)s                                                                        \\
+    } while (0)
+""" % dict(name=name, kind={"ADD": "+ b", "SUB": "- b", "DBL": "* 2"}[kind], KIND=kind, bparam=", b" if has_b else "",
+           decl=decl, body="\\n\\t".join(L), outs=outs, ins=ins if has_b else "", clob=clob, store=store)
+
+    sv = [S(i) for i in range(n)]
+    noscal = sclob
+    sclob = []                                # add / dbl use literals only
+    addm, dblm = macro("ADD", add, True, sv), macro("DBL", dbl, False, sv)
+    sclob = noscal
+    return (addm + dblm + macro("SUB", sub, True, [ACC_LO, ACC_HI]),
+            (len(add), len(dbl), len(sub)))
+
+
 def main(path):
     out = ["/* GENERATED by gen_mont_asm.py — do not edit. */", "#pragma once", ""]
     for cname, c in CURVES.items():
@@ -159,6 +241,10 @@ def main(path):
                 blk, cnt = gen_block_tied("%s_%s" % (cname, fname), p, n)
             out.append("/* %d instructions */" % cnt)
             out.append(blk)
+            if 4 * p <= 1 << (32 * n):
+                blk, cnts = gen_addsub("%s_%s" % (cname, fname), p, n)
+                out.append("/* add / dbl / sub: %d / %d / %d instructions */" % cnts)
+                out.append(blk)
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
 
