@@ -23,27 +23,41 @@ SBASE = 64                                   # s64.. hold the modulus limbs, the
 
 
 def _column_ops(L):
-    """mac / shift emitters for the 96-bit column accumulator.  No register is ever cleared: the very first
-    product uses the constant 0 as its 64-bit addend, and the first carry of every column WRITES the third word
-    (v_addc 0 + 0 + carry) instead of adding into a word that a v_mov would have had to zero."""
-    state = {"first_ever": True, "first_in_column": True}
+    """mac / shift / lo emitters for the 96-bit column accumulator.
+
+    A column's low 64 bits live in an even-aligned VGPR pair (gfx950 requires that of 64-bit operands), its
+    carries in a third register.  Two pairs alternate, A = v[4:5] with carries in v9 and B = v[8:9] with carries
+    in v5: when a column ends, its middle word (the odd register of its pair) is the ONLY thing that has to move
+    — into the even register of the other pair — because the carry word already sits in that pair's odd
+    register.  So a column costs one v_mov; no register is ever cleared either: the very first product uses the
+    constant 0 as its addend, and the first carry of every column WRITES the carry register (0 + 0 + carry)."""
+    pairs = [("v[4:5]", "v4", "v5", "v9"), ("v[8:9]", "v8", "v9", "v5")]     # (pair, lo, mid, carry register)
+    state = {"first_ever": True, "first_in_column": True, "k": 0}
 
     def mac(x, y):
-        addend = "0" if state["first_ever"] else ACC
-        L.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, addend))
+        pair, _lo, _mid, car = pairs[state["k"]]
+        addend = "0" if state["first_ever"] else pair
+        L.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (pair, x, y, addend))
         if state["first_in_column"]:
-            L.append("v_addc_co_u32 %s, vcc, 0, 0, vcc" % ACC2)
+            L.append("v_addc_co_u32 %s, vcc, 0, 0, vcc" % car)
         else:
-            L.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (ACC2, ACC2))
+            L.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (car, car))
         state["first_ever"] = False
         state["first_in_column"] = False
 
     def shift():
-        L.append("v_mov_b32 %s, %s" % (ACC_LO, ACC_HI))
-        L.append("v_mov_b32 %s, %s" % (ACC_HI, ACC2))
+        _pair, _lo, mid, _car = pairs[state["k"]]
+        state["k"] ^= 1
+        L.append("v_mov_b32 %s, %s" % (pairs[state["k"]][1], mid))
         state["first_in_column"] = True
 
-    return mac, shift
+    def lo():
+        return pairs[state["k"]][1]
+
+    return mac, shift, lo
+
+
+ACC_CLOBBERS = ["v4", "v5", "v8", "v9"]
 
 
 def gen_block(name, p, n):
@@ -59,27 +73,27 @@ def gen_block(name, p, n):
     for i, l in enumerate(limbs):
         L.append("s_mov_b32 %s, 0x%08x" % (P(i), l))
     L.append("s_mov_b32 %s, 0x%08x" % (SINV, inv))
-    mac, shift = _column_ops(L)
+    mac, shift, lo = _column_ops(L)
 
     for i in range(n):
         for j in range(i):
             mac(A(j), B(i - j))
             mac(T(j), P(i - j))
         mac(A(i), B(0))
-        L.append("v_mul_lo_u32 %s, %s, %s" % (T(i), ACC_LO, SINV))
+        L.append("v_mul_lo_u32 %s, %s, %s" % (T(i), lo(), SINV))
         mac(T(i), P(0))
         shift()
     for i in range(n, 2 * n):
         for j in range(i - n + 1, n):
             mac(A(j), B(i - j))
             mac(T(j), P(i - j))
-        L.append("v_mov_b32 %s, %s" % (T(i - n), ACC_LO))
+        L.append("v_mov_b32 %s, %s" % (T(i - n), lo()))
         if i < 2 * n - 1:
             shift()
     body = "\\n\\t".join(L)
     outs = ", ".join('"=&v"(t%d)' % i for i in range(n))
     ins = ", ".join('"v"(a.v[%d])' % i for i in range(n)) + ", " + ", ".join('"v"(b.v[%d])' % i for i in range(n))
-    clob = ", ".join('"%s"' % c for c in ["vcc", ACC_LO, ACC_HI, ACC2] + ["s%d" % (SBASE + i) for i in range(n + 1)])
+    clob = ", ".join('"%s"' % c for c in ["vcc"] + ACC_CLOBBERS + ["s%d" % (SBASE + i) for i in range(n + 1)])
     decl = "    u32 " + ", ".join("t%d" % i for i in range(n)) + ";"
     store = " ".join("r.v[%d] = t%d;" % (i, i) for i in range(n))
     return """
@@ -96,7 +110,7 @@ def gen_block(name, p, n):
 """ % dict(name=name, decl=decl, body=body, outs=outs, ins=ins, clob=clob, store=store), len(L)
 
 
-M_BASE = 8                                    # v8.. hold the quotient digits m_j of the tied (12-limb) form
+M_BASE = 10                                   # v10.. hold the quotient digits m_j of the tied (12-limb) form
 
 
 def gen_block_tied(name, p, n):
@@ -114,27 +128,27 @@ def gen_block_tied(name, p, n):
     for i, l in enumerate(limbs):
         L.append("s_mov_b32 %s, 0x%08x" % (P(i), l))
     L.append("s_mov_b32 %s, 0x%08x" % (SINV, inv))
-    mac, shift = _column_ops(L)
+    mac, shift, lo = _column_ops(L)
 
     for i in range(n):
         for j in range(i):
             mac(TA(j), B(i - j))
             mac(M(j), P(i - j))
         mac(TA(i), B(0))
-        L.append("v_mul_lo_u32 %s, %s, %s" % (M(i), ACC_LO, SINV))
+        L.append("v_mul_lo_u32 %s, %s, %s" % (M(i), lo(), SINV))
         mac(M(i), P(0))
         shift()
     for i in range(n, 2 * n):
         for j in range(i - n + 1, n):
             mac(TA(j), B(i - j))
             mac(M(j), P(i - j))
-        L.append("v_mov_b32 %s, %s" % (TA(i - n), ACC_LO))      # a_{i-n} is dead from this column on
+        L.append("v_mov_b32 %s, %s" % (TA(i - n), lo()))      # a_{i-n} is dead from this column on
         if i < 2 * n - 1:
             shift()
     body = "\\n\\t".join(L)
     outs = ", ".join('"+&v"(t%d)' % i for i in range(n))
     ins = ", ".join('"v"(b.v[%d])' % i for i in range(n))
-    clob = ", ".join('"%s"' % c for c in ["vcc", ACC_LO, ACC_HI, ACC2] + ["v%d" % (M_BASE + i) for i in range(n)] +
+    clob = ", ".join('"%s"' % c for c in ["vcc"] + ACC_CLOBBERS + ["v%d" % (M_BASE + i) for i in range(n)] +
                      ["s%d" % (SBASE + i) for i in range(n + 1)])
     decl = "    u32 " + ", ".join("t%d = a.v[%d]" % (i, i) for i in range(n)) + ";"
     store = " ".join("r.v[%d] = t%d;" % (i, i) for i in range(n))
@@ -152,7 +166,7 @@ def gen_block_tied(name, p, n):
 """ % dict(name=name, decl=decl, body=body, outs=outs, ins=ins, clob=clob, store=store), len(L)
 
 
-S_BASE_V = 8                                  # v8.. scratch for the trial subtraction of the lazy add
+S_BASE_V = 10                                 # v8.. scratch for the trial subtraction of the lazy add
 
 
 def gen_addsub(name, p, n):

@@ -31,6 +31,10 @@ constexpr int MSM_MAX_LEVELS = 16;
 constexpr u32 MSM_LVL_L = 8;           // entries per lane on levels >= 1 (short dependent chains)
 constexpr int MSM_WSUM_THREADS = 256;
 constexpr int MSM_SORT_THREADS = 1024;
+// a sorted entry = sign << 31 | table group << gshift | scalar index, gshift = ceil(log2 n) <= 26 (so no division
+// in the accumulate loop); 31 - gshift bits hold the group: >= 5 bits at the largest n, where c >= 13 gives F <= 20,
+// and 64 groups (c = 4) only occur for n < 2^10
+constexpr int MSM_ENTRY_GROUP_SHIFT = 26;
 constexpr int MSM_LDS_COUNTERS = 32768; // 128 KiB of LDS per sort workgroup
 
 struct MsmPlan {
@@ -44,6 +48,7 @@ struct MsmPlan {
     u32 n_levels;
     u32 T[MSM_MAX_LEVELS];     // lanes launched per level
     u32 Lmin0;
+    u32 gshift;       // bit position of the group field in a sorted entry
     u32 chunk;        // scalars per sort workgroup
     u32 K;            // buckets per lane in bucket_reduce
     u32 kconst[10];   // sum_w 2^(c*w + c-1) as 32-bit limbs
@@ -157,7 +162,7 @@ k_msm_scan(const u32* __restrict__ count, u32* __restrict__ start, u32* __restri
 }
 
 // ---- counting sort, pass 2: scatter entry ids ----------------------------------------------------------
-// entry = (group * n + i) | sign << 31
+// entry = sign << 31 | group << p.gshift | i
 template <class Fr>
 __global__ void __launch_bounds__(MSM_SORT_THREADS)
 k_msm_scatter(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __restrict__ cursor,
@@ -196,7 +201,7 @@ k_msm_scatter(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __re
             if (d != 0) {
                 u32 mag = d < 0 ? (u32)(-d) : (u32)d;
                 u32 pos = atomicAdd(&h[(w % p.WP) * p.B + mag - 1], 1u);
-                sorted[pos] = ((w / p.WP) * p.n + (u32)i) | (d < 0 ? 0x80000000u : 0u);
+                sorted[pos] = ((w / p.WP) << p.gshift) | (u32)i | (d < 0 ? 0x80000000u : 0u);
             }
         }
     }
@@ -262,7 +267,7 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
 // VGPRs without spilling (3 waves); wider coordinates keep the compiler's default
 template <class F> struct AccumOcc { static constexpr int waves = 1; };
 template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 4 : 2; };
-template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = 1; };
+template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = P::N <= 8 ? 2 : 1; };   // 207 VGPRs with the asm add/sub
 
 // ---- level 0: equal slices of the sorted entry list, mixed adds into registers ---------------------
 // The sorted list was built for `n_entries` scalars per group; this base table has `n_bases` bases per
@@ -298,9 +303,8 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
             do { b++; boundary = start[b + 1]; } while (boundary <= pos);
         }
         u32 e = sorted[pos];
-        u32 id = e & 0x7fffffffu;
-        u32 g = id / p.n;
-        u32 i = id - g * p.n;
+        u32 g = (e & 0x7fffffffu) >> p.gshift;
+        u32 i = e & ((1u << p.gshift) - 1u);
         if (i >= idx_off && i - idx_off < n_bases) {
             Affine<F> P = ld_vec(&bases[(size_t)g * n_bases + (i - idx_off)]);
             if (e >> 31) P.y = F::neg(P.y);
@@ -469,6 +473,8 @@ inline void msm_set_lanes(MsmPlan& p, u32 max_lanes0) {
 inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) {
     MsmPlan p;
     p.n = n;
+    p.gshift = 1;
+    while (((u64)1 << p.gshift) < n) p.gshift++;
     p.c = c;
     p.B = 1u << (c - 1);
     p.W = (fr_bits + 2 + c - 1) / c;

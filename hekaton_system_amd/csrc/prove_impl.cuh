@@ -425,6 +425,7 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
         return HK_ERR_ARG;
     size_t n_v = d->a_len;
     if (n_v < 1 || d->b_g_len != n_v || d->b_h_len != n_v) return HK_ERR_LEN;
+    if (n_v + d->n_stages + 4 >= ((size_t)1 << MSM_ENTRY_GROUP_SHIFT)) return HK_ERR_ARG;   // sorted-entry index field
     size_t n_wit = 0;
     for (size_t s = 0; s < d->n_stages; s++) n_wit += d->ck_len[s];
     if (d->n_inst < 1 || d->n_inst + n_wit != n_v) return HK_ERR_LEN;   // instance || stage witnesses
@@ -567,7 +568,7 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
             d->C->n_rows != d->n_constraints)
             return fail(HK_ERR_LEN);
         pk->log_m = QapHost<C>::domain_log(d->n_constraints, d->n_inst);
-        if (pk->log_m > C::TWO_ADICITY) return fail(HK_ERR_DOMAIN_TOO_LARGE);
+        if (pk->log_m > C::TWO_ADICITY || pk->log_m > (u32)MSM_ENTRY_GROUP_SHIFT) return fail(HK_ERR_DOMAIN_TOO_LARGE);
         size_t m = (size_t)1 << pk->log_m;
         if (d->h_len + 1 != m) return fail(HK_ERR_LEN);                 // prover.rs:128 assert
         const hk_csr* Ms[3] = {d->A, d->B, d->C};
