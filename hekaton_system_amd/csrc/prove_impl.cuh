@@ -154,7 +154,13 @@ struct NttHost {
                                                 // 64-B rows measured the same alone and less steady under load)
             return v < 1 ? 1u : (v > 10 ? 10u : v);
         }();
-        u32 bottom = logn < (u32)NTT_TILE_LOG ? logn : (u32)NTT_TILE_LOG;
+        static const u32 tile_log = [] {
+            const char* e = getenv("HK_NTT_TILE_LOG");
+            u32 v = e ? (u32)atoi(e) : (u32)NTT_TILE_LOG;
+            return v < 8 ? 8u : (v > (u32)NTT_TILE_LOG ? (u32)NTT_TILE_LOG : v);
+        }();
+        const u32 threads = 1u << (tile_log - 2);                    // one radix-4 quad per thread
+        u32 bottom = logn < tile_log ? logn : tile_log;
         u32 rest = logn - bottom;
         u32 npass = (rest + upper_max - 1) / upper_max;
         struct P { u32 lo, nst, cols_bits; } ps[34];
@@ -163,7 +169,7 @@ struct NttHost {
         u32 lo = bottom;
         for (u32 i = 0; i < npass; i++) {
             u32 nst = (rest - (lo - bottom) + (npass - i) - 1) / (npass - i);
-            ps[np++] = {lo, nst, (u32)NTT_TILE_LOG - nst};
+            ps[np++] = {lo, nst, tile_log - nst};
             lo += nst;
         }
         Fr one = Fr::one();
@@ -177,10 +183,10 @@ struct NttHost {
             const Fr& sc = (pp & 1) ? *ep.scale : one;
             const Fr& kc = (pp & 4) ? *ep.kc : one;
             if (dit)
-                hipLaunchKernelGGL((k_ntt_pass4<Fr, 1>), grid, dim3(NTT_THREADS), lds, s, data, stride, tws, logn, p.lo,
+                hipLaunchKernelGGL((k_ntt_pass4<Fr, 1>), grid, dim3(threads), lds, s, data, stride, tws, logn, p.lo,
                                    p.nst, p.cols_bits, pp, ep.nvec, sc, ep.pw, ep.sub, kc);
             else
-                hipLaunchKernelGGL((k_ntt_pass4<Fr, 0>), grid, dim3(NTT_THREADS), lds, s, data, stride, tws, logn, p.lo,
+                hipLaunchKernelGGL((k_ntt_pass4<Fr, 0>), grid, dim3(threads), lds, s, data, stride, tws, logn, p.lo,
                                    p.nst, p.cols_bits, pp, ep.nvec, sc, ep.pw, ep.sub, kc);
         }
         HK_HIP(hipGetLastError());
