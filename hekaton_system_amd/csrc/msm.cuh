@@ -263,8 +263,8 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
     return lo;
 }
 
-// occupancy the accumulate kernel is compiled for (waves per SIMD): the 8-limb G1 kernel fits 168
-// VGPRs without spilling (3 waves); wider coordinates keep the compiler's default
+// occupancy the accumulate kernel is compiled for (waves per SIMD): 8-limb G1 needs 105 VGPRs (4 waves), 12-limb G1
+// 187 and 8-limb G2 207 (2 waves), 12-limb G2 spills at any occupancy (1 wave)
 template <class F> struct AccumOcc { static constexpr int waves = 1; };
 template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 4 : 2; };
 template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = P::N <= 8 ? 2 : 1; };   // 207 VGPRs with the asm add/sub
