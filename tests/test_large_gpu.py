@@ -180,3 +180,9 @@ def test_concurrent_lanes_match_sequential_and_are_deterministic(ctx_bn254):
 def test_config0_bls12_381_bit_exact_vs_cpu_oracle(ctx_bls):
     """Same shape on the curve BASELINE.json's north_star names: BLS12-381 (6-limb Fq)."""
     _run_config(ctx_bls, "bls12_381", "big-merkle-4x1", check_oracle_prove=True)
+
+
+def test_config1_bls12_381_full_size_properties(ctx_bls):
+    """BASELINE configs[1] shape (m = 2^21) on BLS12-381: proof valid under the trapdoor, quotient polynomial
+    bit-exact vs the CPU oracle."""
+    _run_config(ctx_bls, "bls12_381", "big-merkle-64x32", check_oracle_prove=False)
