@@ -58,7 +58,8 @@ class hk_timings(C.Structure):
 EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk_ctx_sync",
            "hk_ctx_set_profiling", "hk_ctx_last_timings", "hk_ctx_sizes", "hk_dev_alloc", "hk_dev_free",
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
-           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert"]
+           "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
+           "hk_msm_bases"]
 
 _lib = None
 
@@ -95,6 +96,10 @@ def load():
     for f in (lib.hk_scalar_pairing_g1, lib.hk_scalar_pairing_g2):
         f.argtypes = [vp, vp, vp, sz, vp]
     lib.hk_field_convert.argtypes = [vp, i, vp, vp, sz, i]
+    lib.hk_bases_upload.argtypes = [vp, i, vp, sz, C.POINTER(vp)]
+    lib.hk_bases_free.argtypes = [vp]
+    lib.hk_bases_free.restype = None
+    lib.hk_msm_bases.argtypes = [vp, vp, vp, sz, i, i, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -232,6 +237,14 @@ class Context:
         check(fn(self.handle, ptr(points), ptr(scalars), n, out.ctypes.data), fn.__name__)
         return out
 
+    def bases_upload(self, group, bases, n=None):
+        """Makes a static base set resident with its shift tables (hk_bases_upload); returns a ResidentBases."""
+        pb = self.g1_bytes if group == 1 else self.g2_bytes
+        n = n if n is not None else len(bases) // pb
+        h = C.c_void_p()
+        check(self.lib.hk_bases_upload(self.handle, int(group), ptr(bases), n, C.byref(h)), "hk_bases_upload")
+        return ResidentBases(self, h, group, n)
+
     def field_convert(self, which, data, to_mont):
         """Montgomery <-> canonical for a packed array of Fr (`which` = 0) or Fq (1) elements: what ark-ff
         `from_bigint` / `into_bigint` do under ark-serialize.  Returns a new numpy uint8 array."""
@@ -311,6 +324,26 @@ class Context:
         h = C.c_void_p()
         check(self.lib.hk_pk_upload(self.handle, C.byref(d), C.byref(h)), "hk_pk_upload")
         return DevicePk(self, h)
+
+
+class ResidentBases:
+    """hk_bases: a static base set (SRS powers, commitment keys) with its shift tables in HBM."""
+
+    def __init__(self, ctx, handle, group, n):
+        self.ctx, self.handle, self.group, self.n = ctx, handle, group, n
+
+    def msm(self, scalars, n_scalars=None, montgomery=True, checked=True):
+        """`G::Group::msm(&srs_powers, &coeffs)` (distributed-prover/src/kzg.rs:151-152) over the resident bases."""
+        ns = n_scalars if n_scalars is not None else len(scalars) // self.ctx.fr_bytes
+        out = np.zeros(self.ctx.g1_bytes if self.group == 1 else self.ctx.g2_bytes, dtype=np.uint8)
+        check(self.ctx.lib.hk_msm_bases(self.ctx.handle, self.handle, ptr(scalars), ns, int(montgomery), int(checked),
+                                        out.ctypes.data), "hk_msm_bases")
+        return out
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.hk_bases_free(self.handle)
+            self.handle = None
 
 
 class DevicePk:

@@ -106,11 +106,15 @@ struct Ops {
     static hk_status fixed_base(hk_ctx*, int, const void*, const void*, size_t, int, void*);
     static hk_status scalar_pairing(hk_ctx*, int, const void*, const void*, size_t, void*);
     static hk_status field_convert(hk_ctx*, int, const void*, void*, size_t, int);
+    static hk_status bases_upload(hk_ctx*, int, const void*, size_t, hk_bases**);
+    static void bases_free(hk_bases*);
+    static hk_status msm_bases(hk_ctx*, const hk_bases*, const void*, size_t, int, int, void*);
 
     static const CurveOps* table() {
         static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
-                                   &ctx_release, &fixed_base, &scalar_pairing, &field_convert};
+                                   &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
+                                   &bases_free, &msm_bases};
         return &t;
     }
 };

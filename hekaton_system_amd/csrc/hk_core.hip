@@ -225,6 +225,18 @@ hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scal
     if (!ctx || (n && (!points || !scalars || !out))) return HK_ERR_ARG;
     return ctx->ops->scalar_pairing(ctx, 2, points, scalars, n, out);
 }
+hk_status hk_bases_upload(hk_ctx* ctx, int group, const void* bases, size_t n, hk_bases** out) {
+    if (!ctx || !out || (group != 1 && group != 2) || (n && !bases)) return HK_ERR_ARG;
+    return ctx->ops->bases_upload(ctx, group, bases, n, out);
+}
+void hk_bases_free(hk_bases* b) {
+    if (b) b->ops->bases_free(b);
+}
+hk_status hk_msm_bases(hk_ctx* ctx, const hk_bases* b, const void* scalars, size_t n_scalars, int mont, int checked,
+                       void* out) {
+    if (!ctx || !b || !out || b->ctx != ctx) return HK_ERR_ARG;
+    return ctx->ops->msm_bases(ctx, b, scalars, n_scalars, mont, checked, out);
+}
 hk_status hk_field_convert(hk_ctx* ctx, int which, const void* in, void* out, size_t n, int to_mont) {
     if (!ctx || (which != 0 && which != 1) || (n && (!in || !out))) return HK_ERR_ARG;
     return ctx->ops->field_convert(ctx, which, in, out, n, to_mont);

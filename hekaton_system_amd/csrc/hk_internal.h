@@ -105,6 +105,10 @@ struct CurveOps {
                             void* out);
     hk_status (*scalar_pairing)(hk_ctx*, int group, const void* points, const void* scalars, size_t n, void* out);
     hk_status (*field_convert)(hk_ctx*, int which, const void* in, void* out, size_t n, int to_mont);
+    hk_status (*bases_upload)(hk_ctx*, int group, const void* bases, size_t n, hk_bases** out);
+    void (*bases_free)(hk_bases*);
+    hk_status (*msm_bases)(hk_ctx*, const hk_bases*, const void* scalars, size_t n_scalars, int mont, int checked,
+                           void* out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();
@@ -125,6 +129,12 @@ struct hk_ctx {
 };
 
 struct hk_pk {
+    const hk::CurveOps* ops;
+    hk_ctx* ctx;
+    void* impl;
+};
+
+struct hk_bases {
     const hk::CurveOps* ops;
     hk_ctx* ctx;
     void* impl;

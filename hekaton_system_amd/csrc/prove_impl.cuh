@@ -625,6 +625,90 @@ void Ops<C>::pk_free(hk_pk* h) {
     delete h;
 }
 
+// ---- MSM over a resident base set (hk_bases_*) -------------------------------------------------------------
+struct BasesImpl {
+    int group = 1;
+    u32 n = 0;
+    MsmPlan plan;
+    void* tab = nullptr;        // [F][n] Affine<Fq> or Affine<Fq2>
+    size_t bytes = 0;
+};
+
+template <class C>
+hk_status Ops<C>::bases_upload(hk_ctx* ctx, int group, const void* bases, size_t n, hk_bases** out) {
+    *out = nullptr;
+    if (n >= ((size_t)1 << MSM_ENTRY_GROUP_SHIFT)) return HK_ERR_ARG;
+    HK_HIP(hipSetDevice(ctx->device));
+    BasesImpl* b = new BasesImpl();
+    b->group = group;
+    b->n = (u32)n;
+    hk_bases* h = new hk_bases{ctx->ops, ctx, b};
+    if (n == 0) { *out = h; return HK_OK; }
+    b->plan = msm_make_plan((u32)n, C::FR_BITS, msm_pick_c_tables(n, C::FR_BITS), 1u, ctx->max_lanes0);
+    auto build = [&](auto ftag) -> hk_status {
+        typedef decltype(ftag) F;
+        size_t bytes = (size_t)b->plan.F * n * sizeof(Affine<F>);
+        if (hipMalloc(&b->tab, bytes) != hipSuccess) { (void)hipGetLastError(); return HK_ERR_NOMEM; }
+        b->bytes = bytes;
+        HK_HIP(hipMemcpy(b->tab, bases, n * sizeof(Affine<F>), h2d_kind(bases)));
+        return MsmRun<F>::build_tables(0, (Affine<F>*)b->tab, (u32)n, b->plan.F, b->plan.c * b->plan.WP);
+    };
+    hk_status st = group == 1 ? build(Fq()) : build(Fq2());
+    if (st == HK_OK && hipDeviceSynchronize() != hipSuccess) st = HK_ERR_DEVICE;
+    if (st != HK_OK) { Ops<C>::bases_free(h); return st; }
+    *out = h;
+    return HK_OK;
+}
+
+template <class C>
+void Ops<C>::bases_free(hk_bases* h) {
+    if (!h) return;
+    BasesImpl* b = (BasesImpl*)h->impl;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (b->tab) (void)hipFree(b->tab);
+    delete b;
+    delete h;
+}
+
+template <class C>
+hk_status Ops<C>::msm_bases(hk_ctx* ctx, const hk_bases* h, const void* scalars, size_t n_scalars, int mont,
+                            int checked, void* out) {
+    const BasesImpl* b = (const BasesImpl*)h->impl;
+    if (checked && n_scalars != b->n) return HK_ERR_LEN;            // ark `msm`: Err(min_len)
+    size_t n = n_scalars < b->n ? n_scalars : b->n;                 // ark `msm_unchecked`: zip
+    auto run = [&](auto ftag) -> hk_status {
+        typedef decltype(ftag) F;
+        if (n == 0) { memset(out, 0, sizeof(Affine<F>)); return HK_OK; }
+        if (!scalars) return HK_ERR_ARG;
+        LaneGuard g(ctx);
+        Lane* L = g.lane;
+        if (!L) return HK_ERR_DEVICE;
+        const MsmPlan& p = b->plan;                                  // planned for b->n scalars; the tail reads zeros
+        size_t need = al256(b->n * sizeof(Fr)) + msm_sort_bytes(p) + msm_run_bytes<F>(p) + 8192;
+        HK_TRY(L->reserve(need));
+        hipStream_t s = L->stream;
+        Fr* sc = L->alloc_n<Fr>(b->n);
+        if (!sc) return HK_ERR_NOMEM;
+        HK_HIP(hipMemcpyAsync(sc, scalars, n * sizeof(Fr), h2d_kind(scalars), s));
+        if (n < b->n) HK_HIP(hipMemsetAsync(sc + n, 0, (b->n - n) * sizeof(Fr), s));
+        SortBufs sb;
+        HK_TRY(MsmSort<Fr>::alloc(L, p, &sb));
+        typename MsmRun<F>::Bufs rb;
+        HK_TRY(MsmRun<F>::alloc(L, p, &rb));
+        XYZZ<F>* res = L->alloc_n<XYZZ<F>>(1);
+        Affine<F>* aff = L->alloc_n<Affine<F>>(1);
+        if (!res || !aff) return HK_ERR_NOMEM;
+        HK_TRY(MsmSort<Fr>::run(s, p, (const u32*)sc, mont, sb));
+        HK_TRY(MsmRun<F>::run(s, p, (const Affine<F>*)b->tab, b->n, 0, sb, rb, res, nullptr, nullptr));
+        HK_TRY(MsmRun<F>::to_affine(s, res, aff, 1));
+        HK_HIP(hipMemcpyAsync(out, aff, sizeof(Affine<F>), is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        HK_HIP(hipStreamSynchronize(s));
+        return HK_OK;
+    };
+    return b->group == 1 ? run(Fq()) : run(Fq2());
+}
+
 template <class C>
 hk_status Ops<C>::fixed_base(hk_ctx* ctx, int group, const void* base, const void* scalars, size_t n, int mont,
                              void* out) {

@@ -162,6 +162,21 @@ hk_status hk_fixed_base_g2(hk_ctx* ctx, const void* base, const void* scalars, s
 hk_status hk_scalar_pairing_g1(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
 hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
 
+/* ---- MSM over a RESIDENT base set ----------------------------------------------------------------------
+ * Bases that are key material (the KZG / commitment-key powers of the aggregator's SRS, any static query) are
+ * uploaded once together with their 2^(16 g) multiples, exactly like the proving-key queries; every later MSM over
+ * them then has no Horner tail (the 254 sequential doublings that bound a one-off MSM's latency).
+ * replaces `G::Group::msm(&srs_powers_alpha, &witness_poly.coeffs)` / `..beta..` of the KZG openings
+ * (distributed-prover/src/kzg.rs:151-152) and the static-key MSMs of TIPA (distributed-prover/src/aggregation.rs:337,
+ * third-party ripp) once the SRS of `TIPA::setup` (aggregation.rs:60-135) is resident.
+ * group: 1 = G1, 2 = G2.  hk_msm_bases: same scalar conventions and length semantics as hk_msm_g1/g2
+ * (checked != 0: n_scalars must equal the number of bases, else HK_ERR_LEN; unchecked: zip to the shorter). */
+typedef struct hk_bases hk_bases;
+hk_status hk_bases_upload(hk_ctx* ctx, int group, const void* bases, size_t n, hk_bases** out);
+void      hk_bases_free(hk_bases* b);
+hk_status hk_msm_bases(hk_ctx* ctx, const hk_bases* b, const void* scalars, size_t n_scalars, int mont,
+                       int checked, void* out);
+
 /* Montgomery <-> canonical conversion of n field elements (which: 0 = Fr, 1 = Fq; to_mont != 0: out = in*R mod p,
  * else out = in/R mod p; canonical input must be < p).  in/out are host or device pointers and may alias.
  * replaces ark-ff `into_bigint()` / `from_bigint()` as ark-serialize calls them for every field element of a key

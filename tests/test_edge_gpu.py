@@ -121,3 +121,41 @@ def test_scalar_pairing_like_reference(group, ctx_bn254):
     out = ctx_bn254.scalar_pairing(group, enc(pts), cd.fr_vec_mont(scal))
     got = [dec(out[i * pb:(i + 1) * pb]) for i in range(n)]
     assert got == [G.mul(p, s) if p is not None else None for p, s in zip(pts, scal)]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_resident_bases_msm_matches_plain_msm_and_oracle(group, ctx_bn254):
+    """hk_bases_upload / hk_msm_bases (the aggregator's static-SRS MSMs, kzg.rs:151-152): same group element as the
+    one-off hk_msm over the same bases and as the oracle's Pippenger; ark length semantics."""
+    from hekaton_system_amd.cp_groth16 import CURVE_PARAMS, FrCodec
+    from oracle.c_oracle import COracle
+    fc = FrCodec("bn254")
+    p = CURVE_PARAMS["bn254"]
+    rnd = random.Random(40 + group)
+    gen = fc.g1(p["g1"]) if group == 1 else fc.g2(p["g2"])
+    co = COracle("bn254")
+    msm = ctx_bn254.msm_g1 if group == 1 else ctx_bn254.msm_g2
+    pb = ctx_bn254.g1_bytes if group == 1 else ctx_bn254.g2_bytes
+    for n in (1, 2, 64, 1000, 5000):
+        bases = ctx_bn254.fixed_base(group, gen, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)]))
+        if n > 2:
+            bases[pb:2 * pb] = 0                                    # an infinity base in the set
+        rb = ctx_bn254.bases_upload(group, bases)
+        for dense in (True, False):
+            sc = fc.enc([rnd.randrange(p["r"]) if (dense or rnd.random() < 0.15) else rnd.randrange(2) for _ in range(n)])
+            got = rb.msm(sc)
+            assert np.array_equal(got, msm(bases, sc))
+            assert np.array_equal(got, co.msm(group, bases, sc))
+        # canonical (non-Montgomery) scalars, as msm_bigint takes them
+        ints = [rnd.randrange(p["r"]) for _ in range(n)]
+        assert np.array_equal(rb.msm(fc.enc_canon(ints), montgomery=False), rb.msm(fc.enc(ints)))
+        if n >= 64:
+            short = fc.enc([rnd.randrange(p["r"]) for _ in range(n - 7)])
+            with pytest.raises(capi.HekatonError) as e:             # msm: Err(min_len)
+                rb.msm(short)
+            assert e.value.status == capi.HK_ERR_LEN
+            assert np.array_equal(rb.msm(short, checked=False), msm(bases, short, checked=False))   # msm_unchecked zips
+        rb.free()
+    empty = ctx_bn254.bases_upload(group, np.zeros(0, np.uint8), n=0)
+    assert not empty.msm(np.zeros(0, np.uint8)).any()
+    empty.free()
