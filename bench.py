@@ -179,6 +179,8 @@ def main():
         # Algorithmic bytes per launch = terms * (32 + S1)  (SURVEY.md §8d "MSM-G1 = n*(32+S1)"), averaged
         # over the same launches whose durations are averaged — the population rocprofv3 --stats averages.
         n1 = circ.n_v - circ.N_INST - circ.n0
+        fq_limbs = ctx.fq_bytes // 4
+        nwin = (ctx.fr_bytes * 8 + 1 + 15) // 16 if args.curve == "bls12_381" else 16      # ceil((bits+2)/16): 16 / 17
         terms = [m - 1, circ.n_v - 1, circ.n_v - 1, n1, circ.n0]
         alg_bytes = sum(terms) * (32 + g1) / len(terms)
         avg_ms = float(np.sum(accum_ms) / max(1, np.sum(accum_n))) if accum_ms else float("nan")
@@ -210,7 +212,15 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                          "h_query_launch": {"alg_bytes": (m - 1) * (32 + g1), "avg_ms": h_ms,
-                                            "achieved": (m - 1) * (32 + g1) / (h_ms * 1e-3) / 1e9}},
+                                            "achieved": (m - 1) * (32 + g1) / (h_ms * 1e-3) / 1e9},
+                         # the bound that actually binds: integer multiply issue.  One mixed add = 10 Montgomery
+                         # products of 2*N^2 v_mad_u64_u32 each (N = 8 / 12 limbs); peak = the measured chip-wide
+                         # v_mad_u64_u32 rate (tools/ubench.hip: 24.7 Top/s) / mads per product
+                         "valu": {"unit": "G field mults/s",
+                                  "achieved": (m - 1) * nwin * 10 / (h_ms * 1e-3) / 1e9,
+                                  "peak": 24.7e3 / (2 * (fq_limbs ** 2)),
+                                  "frac": (m - 1) * nwin * 10 / (h_ms * 1e-3) / 1e9 / (24.7e3 / (2 * (fq_limbs ** 2))),
+                                  "note": "H-query launch: (m-1) scalars x %d signed 16-bit digits x 10 products per mixed add" % nwin}},
             "phase_ms_per_proof": {k: v / nprov for k, v in phase.items() if k.endswith("_ms")},
         }
         if keep_host:
