@@ -82,7 +82,7 @@ HK_RARE XYZZ<F> ec_dbl_rare(const XYZZ<F>& p) { return ec_dbl(p); }
 // the P == Q corner: an out-of-line call there takes the addresses of `a`/`q`, which forces hipcc to
 // keep copies of them in scratch memory on EVERY iteration of the accumulate loop (rocprofv3 showed
 // 6.3 GB of WRITE_SIZE per 2^21-point MSM from it).
-template <class F>
+template <class F, bool INLINE_CORNER = (F::Params::N <= 8)>
 HK_HD XYZZ<F> ec_madd(const XYZZ<F>& a, const Affine<F>& q) {
     if (q.is_inf()) return a;
     if (a.is_inf()) return XYZZ<F>::from_affine(q);
@@ -93,9 +93,10 @@ HK_HD XYZZ<F> ec_madd(const XYZZ<F>& a, const Affine<F>& q) {
     XYZZ<F> o;
     if (p.is_zero()) {
         if (!r.is_zero()) return XYZZ<F>::inf();
-        // 12-limb coordinate fields keep the out-of-line form: their kernels are at the edge of what
-        // hipcc/gfx950 handles (see the note at ec_dbl_rare and DESIGN.md), and are not the benched path
-        if constexpr (F::Params::N > 8) return ec_dbl_affine(q);
+        // 12-limb coordinate fields keep the out-of-line form by default: their G2 kernels are at the edge of
+        // what hipcc/gfx950 handles (see the note at ec_dbl_rare and DESIGN.md); the G1 accumulate loop asks for the
+        // inline form explicitly (145 VGPRs and no scratch instead of 187 VGPRs and 304 B of scratch per lane)
+        if constexpr (!INLINE_CORNER) return ec_dbl_affine(q);
         // doubling of the affine point ("mdbl-2008-s-1", a = 0)
         F u = F::dbl(q.y);
         F v = F::sqr(u);

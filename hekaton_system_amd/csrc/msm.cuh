@@ -264,9 +264,12 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
 }
 
 // occupancy the accumulate kernel is compiled for (waves per SIMD): 8-limb G1 needs 105 VGPRs (4 waves), 12-limb G1
-// 187 and 8-limb G2 207 (2 waves), 12-limb G2 spills at any occupancy (1 wave)
+// 145 (3 waves), 8-limb G2 207 (2 waves), 12-limb G2 spills at any occupancy (1 wave)
+// the accumulate loop inlines the P == Q corner of the mixed add for every base field (G1); G2 follows the default
+template <class F> struct AccumInlineCorner { static constexpr bool value = F::Params::N <= 8; };
+template <class P> struct AccumInlineCorner<Fp<P>> { static constexpr bool value = true; };
 template <class F> struct AccumOcc { static constexpr int waves = 1; };
-template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 4 : 2; };
+template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 4 : 3; };
 template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = P::N <= 8 ? 2 : 1; };   // 207 VGPRs with the asm add/sub
 
 // ---- level 0: equal slices of the sorted entry list, mixed adds into registers ---------------------
@@ -308,7 +311,7 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
         if (i >= idx_off && i - idx_off < n_bases) {
             Affine<F> P = ld_vec(&bases[(size_t)g * n_bases + (i - idx_off)]);
             if (e >> 31) P.y = F::neg(P.y);
-            acc = ec_madd(acc, P);
+            acc = ec_madd<F, AccumInlineCorner<F>::value>(acc, P);
         }
     }
     bool tail_partial = end < boundary;     // bucket b continues in the next lane's slice
