@@ -136,6 +136,7 @@ struct Fp {
         // lazy fields: carry chain in VCC, 3N VALU instructions (gen_mont_asm.py gen_addsub)
         if constexpr (P::LAZY && P::ASM_ID == 1) { Fp r; HK_ADD_ASM_BN254_FR(r, a, b); return r; }
         if constexpr (P::LAZY && P::ASM_ID == 2) { Fp r; HK_ADD_ASM_BN254_FQ(r, a, b); return r; }
+        if constexpr (!P::LAZY && P::ASM_ID == 3) { Fp r; HK_ADD_ASM_BLS12_381_FR(r, a, b); return r; }   // canonical
         if constexpr (P::LAZY && P::ASM_ID == 4) { Fp r; HK_ADD_ASM_BLS12_381_FQ(r, a, b); return r; }
 #endif
         Fp t;
@@ -152,6 +153,7 @@ struct Fp {
 #if defined(HK_USE_ASM_MUL)
         if constexpr (P::LAZY && P::ASM_ID == 1) { Fp r; HK_DBL_ASM_BN254_FR(r, a); return r; }
         if constexpr (P::LAZY && P::ASM_ID == 2) { Fp r; HK_DBL_ASM_BN254_FQ(r, a); return r; }
+        if constexpr (!P::LAZY && P::ASM_ID == 3) { Fp r; HK_DBL_ASM_BLS12_381_FR(r, a); return r; }
         if constexpr (P::LAZY && P::ASM_ID == 4) { Fp r; HK_DBL_ASM_BLS12_381_FQ(r, a); return r; }
 #endif
         return add(a, a);
@@ -161,6 +163,7 @@ struct Fp {
 #if defined(HK_USE_ASM_MUL)
         if constexpr (P::LAZY && P::ASM_ID == 1) { Fp r; HK_SUB_ASM_BN254_FR(r, a, b); return r; }
         if constexpr (P::LAZY && P::ASM_ID == 2) { Fp r; HK_SUB_ASM_BN254_FQ(r, a, b); return r; }
+        if constexpr (!P::LAZY && P::ASM_ID == 3) { Fp r; HK_SUB_ASM_BLS12_381_FR(r, a, b); return r; }
         if constexpr (P::LAZY && P::ASM_ID == 4) { Fp r; HK_SUB_ASM_BLS12_381_FQ(r, a, b); return r; }
 #endif
         Fp t;
@@ -201,7 +204,7 @@ struct Fp {
         // hand-scheduled product-scanning form (gen_mont_asm.py): 128 mad+addc pairs, no pair shuffles
         if constexpr (P::ASM_ID == 1) { Fp r; HK_MONT_ASM_BN254_FR(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
         if constexpr (P::ASM_ID == 2) { Fp r; HK_MONT_ASM_BN254_FQ(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
-        if constexpr (P::ASM_ID == 3) { Fp r; HK_MONT_ASM_BLS12_381_FR(r, a, b); return reduce_once(r); }
+        if constexpr (P::ASM_ID == 3) { Fp t, r; HK_MONT_ASM_BLS12_381_FR(t, a, b); HK_RED_ASM_BLS12_381_FR(r, t); return r; }
         if constexpr (P::ASM_ID == 4) { Fp r; HK_MONT_ASM_BLS12_381_FQ(r, a, b); if constexpr (P::LAZY) return r; else return reduce_once(r); }
 #endif
         u32 t[N + 1];

@@ -170,11 +170,13 @@ S_BASE_V = 10                                 # v8.. scratch for the trial subtr
 
 
 def gen_addsub(name, p, n):
-    """Lazy-form ([0, 2p) in, [0, 2p) out) modular add / sub / double with the carry chain in VCC:
-    3n VALU instructions each, against ~6n for what hipcc makes of the portable u64 loops."""
+    """Modular add / sub / double with the carry chain in VCC: 3n VALU instructions each, against ~6n for what
+    hipcc makes of the portable u64 loops.  Lazy fields (4p <= R) work on [0, 2p) representatives and reduce
+    against 2p; the others (BLS12-381 Fr) on canonical values against p (a + b < 2p < R still holds)."""
     R = 1 << (32 * n)
-    assert 4 * p <= R
-    p2 = [((2 * p) >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+    bound = 2 * p if 4 * p <= R else p
+    assert 2 * bound <= R
+    p2 = [(bound >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
     T = lambda i: "%%%d" % i                  # "+v": a_i in, result out
     B = lambda i: "%%%d" % (n + i)
     P = lambda i: "s%d" % (SBASE + i)
@@ -223,7 +225,7 @@ def gen_addsub(name, p, n):
         nonlocal sclob
         clob = ", ".join('"%s"' % c for c in ["vcc"] + clob_v + sclob)
         return """
-// %(name)s: r = a %(kind)s mod p on [0, 2p) representatives
+// %(name)s: r = a %(kind)s mod p on [0, %(bound)s) representatives
 #define HK_%(KIND)s_ASM_%(name)s(r, a%(bparam)s)                                          \\
     do {                                                                                 \\
     %(decl)s                                                                             \\
@@ -233,13 +235,15 @@ def gen_addsub(name, p, n):
             : %(clob)s);                                                                 \\
         %(store)s                                                                        \\
     } while (0)
-""" % dict(name=name, kind={"ADD": "+ b", "SUB": "- b", "DBL": "* 2"}[kind], KIND=kind, bparam=", b" if has_b else "",
+""" % dict(name=name, bound="2p" if bound == 2 * p else "p", kind={"ADD": "+ b", "SUB": "- b", "DBL": "* 2", "RED": "(one conditional subtraction of the bound)"}[kind], KIND=kind, bparam=", b" if has_b else "",
            decl=decl, body="\\n\\t".join(L), outs=outs, ins=ins if has_b else "", clob=clob, store=store)
 
+    red = []
+    trial_sub(red)
     sv = [S(i) for i in range(n)]
     noscal = sclob
     sclob = []                                # add / dbl use literals only
-    addm, dblm = macro("ADD", add, True, sv), macro("DBL", dbl, False, sv)
+    addm, dblm = macro("ADD", add, True, sv), macro("DBL", dbl, False, sv) + macro("RED", red, False, sv)
     sclob = noscal
     return (addm + dblm + macro("SUB", sub, True, [ACC_LO, ACC_HI]),
             (len(add), len(dbl), len(sub)))
@@ -255,7 +259,7 @@ def main(path):
                 blk, cnt = gen_block_tied("%s_%s" % (cname, fname), p, n)
             out.append("/* %d instructions */" % cnt)
             out.append(blk)
-            if 4 * p <= 1 << (32 * n):
+            if True:
                 blk, cnts = gen_addsub("%s_%s" % (cname, fname), p, n)
                 out.append("/* add / dbl / sub: %d / %d / %d instructions */" % cnts)
                 out.append(blk)
