@@ -106,6 +106,11 @@ struct Fp {
 
     // r = a - MOD if a >= MOD (a < 2*MOD, carry-free because MOD has a spare top bit)
     HK_HD static Fp reduce_once(const Fp& a) {
+#if defined(HK_USE_ASM_MUL)
+        if constexpr (P::LAZY && P::ASM_ID == 1) { Fp r; HK_CANON_ASM_BN254_FR(r, a); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 2) { Fp r; HK_CANON_ASM_BN254_FQ(r, a); return r; }
+        if constexpr (P::LAZY && P::ASM_ID == 4) { Fp r; HK_CANON_ASM_BLS12_381_FQ(r, a); return r; }
+#endif
         Fp s;
         u64 borrow = 0;
         HK_UNROLL for (int i = 0; i < N; i++) {

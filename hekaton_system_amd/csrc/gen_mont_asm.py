@@ -235,15 +235,27 @@ def gen_addsub(name, p, n):
             : %(clob)s);                                                                 \\
         %(store)s                                                                        \\
     } while (0)
-""" % dict(name=name, bound="2p" if bound == 2 * p else "p", kind={"ADD": "+ b", "SUB": "- b", "DBL": "* 2", "RED": "(one conditional subtraction of the bound)"}[kind], KIND=kind, bparam=", b" if has_b else "",
+""" % dict(name=name, bound="2p" if bound == 2 * p else "p", kind={"ADD": "+ b", "SUB": "- b", "DBL": "* 2", "RED": "(one conditional subtraction of the bound)", "CANON": "(one conditional subtraction of p: [0, 2p) -> [0, p))"}[kind], KIND=kind, bparam=", b" if has_b else "",
            decl=decl, body="\\n\\t".join(L), outs=outs, ins=ins if has_b else "", clob=clob, store=store)
 
     red = []
     trial_sub(red)
+    canon = []
+    if bound != p:                            # lazy field: memory form is canonical, one more subtraction of p
+        p1 = [(p >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+        for i in range(n):
+            canon.append("v_mov_b32 %s, 0x%08x" % (S(i), p1[i]))
+        canon.append("v_sub_co_u32 %s, vcc, %s, %s" % (S(0), T(0), S(0)))
+        for i in range(1, n):
+            canon.append("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (S(i), T(i), S(i)))
+        for i in range(n):
+            canon.append("v_cndmask_b32 %s, %s, %s, vcc" % (T(i), S(i), T(i)))
     sv = [S(i) for i in range(n)]
     noscal = sclob
     sclob = []                                # add / dbl use literals only
     addm, dblm = macro("ADD", add, True, sv), macro("DBL", dbl, False, sv) + macro("RED", red, False, sv)
+    if canon:
+        dblm += macro("CANON", canon, False, sv)
     sclob = noscal
     return (addm + dblm + macro("SUB", sub, True, [ACC_LO, ACC_HI]),
             (len(add), len(dbl), len(sub)))
