@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--threads", type=int, default=8, help="host threads (= GPU lanes) proving concurrently")
     ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="hand every assignment over from host memory (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None,
                     help="force a device index (rehearsing N > 1 ranks on a 1-GPU box with --backend gloo)")
@@ -121,8 +123,9 @@ def main():
     zs, w0s = [], []
     for k in range(args.witnesses):
         circ.set_witness_seed(1000 * rank + k + 1)
-        zs.append(capi.DeviceBuffer.from_host(ctx, circ.full_assignment_bytes()))
-        w0s.append(capi.DeviceBuffer.from_host(ctx, circ.stage0_witness_bytes()))
+        zb, wb = circ.full_assignment_bytes(), circ.stage0_witness_bytes()
+        zs.append(zb if args.host_inputs else capi.DeviceBuffer.from_host(ctx, zb))
+        w0s.append(wb if args.host_inputs else capi.DeviceBuffer.from_host(ctx, wb))
     r_b, s_b, kap = fc.enc1(0x1234567), fc.enc1(0x7654321), fc.enc([0x5555])
     ctx.set_profiling(True)
     accum_ms, accum_n, accum_h, phase = [], [], [], {}
@@ -203,7 +206,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (Montgomery mod-p integers)",
             "data": "synthetic (SHA-like 85%% small / 15%% full-width witnesses, genuine Groth16 SRS from a "
-                    "seeded trapdoor; %d distinct assignments cycled)" % args.witnesses,
+                    "seeded trapdoor; %d distinct assignments cycled%s)" % (
+                        args.witnesses, "; assignments copied from pageable host memory per proof" if args.host_inputs else ""),
             "config": {"workload": args.config, "curve": args.curve, "subcircuits_per_gpu_per_step": args.subcircuits,
                        "n_constraints": circ.n_c, "n_variables": circ.n_v, "domain": m,
                        "host_threads_per_gpu": args.threads, "sharding": "subcircuits/%d per rank" % world},
