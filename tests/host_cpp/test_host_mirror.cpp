@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <fstream>
 #include <iterator>
-#include "../../hekaton_system_amd/csrc/host/cp_groth16.hpp"
+#include "../../hekaton_system_amd/csrc/host/ark_serialize.hpp"
 using namespace hekaton;
 
 static Bytes rd(const std::string& dir, const std::string& name) {
@@ -68,8 +68,27 @@ int main(int argc, char** argv) {
         // error behaviour: comm_rands of the wrong length (committer.rs:112)
         bool threw = false;
         try { CommitmentBuilder cb2(ctx, circ, pk, one); cb2.commit(commit_rng); cb2.prove({}, {}, prove_rng); } catch (const std::logic_error&) { threw = true; }
-        printf("%s\n", ok && threw ? "HOST_MIRROR_OK" : "HOST_MIRROR_MISMATCH");
-        return ok && threw ? 0 : 1;
+        // wire formats: the C++ codec against the bytes the Python mirror produced for the same records
+        ArkCodecBn254 codec(ctx);
+        Stage0Response r0{7, cr.first, {}};
+        Bytes seed = rd(d, "seed");
+        memcpy(r0.com_seed.data(), seed.data(), 32);
+        Stage1Response r1{7, p};
+        Bytes w0 = codec.stage0_response_to_wire(r0), w1 = codec.stage1_response_to_wire(r1);
+        bool wire = w0 == rd(d, "expect_wire0") && w1 == rd(d, "expect_wire1") && w0.size() == 104 && w1.size() == 336;
+        Stage0Response b0 = codec.stage0_response_from_wire(w0);
+        Stage1Response b1 = codec.stage1_response_from_wire(w1);
+        wire = wire && b0.com == cr.first && b0.subcircuit_idx == 7 && b0.com_seed == r0.com_seed && b1.proof.a == p.a &&
+               b1.proof.b == p.b && b1.proof.c == p.c && b1.proof.ds.size() == 1 && b1.proof.ds[0] == cr.first;
+        wire = wire && codec.points_to_wire(1, p.a, true) == rd(d, "expect_a_compressed") &&
+               codec.points_to_wire(2, p.b, true) == rd(d, "expect_b_compressed");
+        wire = wire && ArkCodecBn254::to_packed(w1).size() == 512;
+        // kappa = Fr::rand(ChaCha12Rng::from_seed(com_seed))
+        bool rngok = commitment_randomness_bn254(r0.com_seed) == rd(d, "expect_kappa_from_seed");
+        bool all = ok && threw && wire && rngok;
+        if (!all) fprintf(stderr, "ok=%d threw=%d wire=%d rng=%d\n", ok, threw, wire, rngok);
+        printf("%s\n", all ? "HOST_MIRROR_OK" : "HOST_MIRROR_MISMATCH");
+        return all ? 0 : 1;
     } catch (const std::exception& e) {
         fprintf(stderr, "exception: %s\n", e.what());
         return 3;
