@@ -55,7 +55,7 @@ def parse():
 
 def cpu_baseline(args, circ, pk_host, fc):
     """The CPU restatement of the ark-ec/ark-poly path (oracle/c, kind "port") timed on this box's
-    host cores over ONE subcircuit of the same workload (commit + prove)."""
+    host cores over a bounded sample of the same workload: three subcircuits, commit + prove each."""
     import shutil
     import tempfile
     from oracle import c_oracle
@@ -69,16 +69,19 @@ def cpu_baseline(args, circ, pk_host, fc):
     cores = co.threads()
     view = co.pk_view(**pk_host["points"])
     A, B, C = pk_host["matrices"]
-    circ.set_witness_seed(1)
-    z = circ.full_assignment_bytes()
-    w0 = circ.stage0_witness_bytes()
     kap = fc.enc([7])
+    n_sample = 3                                   # ~15 s of CPU work on the GPU box's host cores
+    inputs = []
+    for seed in range(1, n_sample + 1):
+        circ.set_witness_seed(seed)
+        inputs.append((circ.full_assignment_bytes(), circ.stage0_witness_bytes()))
     t0 = time.time()
-    co.commit(view, 0, w0, kap)
-    co.prove(view, A, B, C, circ.N_INST, circ.n_c, z, fc.enc1(11), fc.enc1(13), kap)
+    for z, w0 in inputs:
+        co.commit(view, 0, w0, kap)
+        co.prove(view, A, B, C, circ.N_INST, circ.n_c, z, fc.enc1(11), fc.enc1(13), kap)
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": "1 subcircuit (1 commit + 1 prove) of %s, %.1f s" % (args.config, dt)}
+    return {"value": n_sample / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "%d subcircuits (1 commit + 1 prove each) of %s, %.1f s" % (n_sample, args.config, dt)}
 
 
 def main():
