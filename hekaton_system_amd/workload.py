@@ -28,9 +28,70 @@ CONFIGS = {
     "big-merkle-4x1": dict(n_c=61_000, n_free=4_000, n0=16),          # config 0: m = 2^16
     "big-merkle-64x32": dict(n_c=1_250_000, n_free=50_000, n0=16),    # config 1: m = 2^21, n_v ~ 1.3e6
     "big-merkle-512x64": dict(n_c=2_500_000, n_free=100_000, n0=16),  # config 2: m = 2^22, n_v ~ 2.6e6
+    # config 3: the per-subcircuit size of vkd is unknown offline ("placeholder 2^17; must be measured");
+    # flagged placeholder m = 2^17, n0 = 8 192 ("portal-heavy"), 7 proving-key classes
+    "vkd-256": dict(n_c=120_000, n_free=12_000, n0=8_192),
     "vm-1024x1024": dict(n_c=1_000_000, n_free=700_000, n0=217_280),  # config 4: m = 2^20, n_v ~ 1.7e6
     "tiny": dict(n_c=1_000, n_free=100, n0=16),
 }
+
+# circuit family and number of subcircuits of every BASELINE config: which proving-key class a subcircuit index
+# uses is the family's `representative_subcircuit` (below)
+FAMILIES = {
+    "big-merkle-4x1": ("big-merkle", 4), "big-merkle-64x32": ("big-merkle", 64),
+    "big-merkle-512x64": ("big-merkle", 512), "vkd-256": ("vkd", 256), "vm-1024x1024": ("vm", 1024),
+    "tiny": ("big-merkle", 8),
+}
+
+
+def unique_subcircuits(family, n):
+    """`CircuitWithPortals::get_unique_subcircuits`: one representative index per proving-key class.
+    big-merkle: tree_hash_circuit.rs:192-197; vkd: vkd/vkd_constraints.rs:199-201; vm: vm/vm_constraints.rs:91-93."""
+    if family == "big-merkle":
+        out = [0, 1, n - 1, n - 2, n - 3]
+    elif family == "vkd":
+        out = [0, 6, 7, 8, 10, 19, n - 1]
+    elif family == "vm":
+        out = [0, 1]
+    else:
+        raise KeyError(family)
+    seen = []
+    for x in out:                      # tiny trees (n = 4) name the same index twice
+        if x not in seen:
+            seen.append(x)
+    return seen
+
+
+def representative_subcircuit(family, n, idx):
+    """`CircuitWithPortals::representative_subcircuit`: subcircuit index -> index of its class representative.
+    big-merkle: tree_hash_circuit.rs:200-216 (first leaf, other leaves, parents, root, padding);
+    vkd: vkd/vkd_constraints.rs:203-214 over the layout `vkd_update_to_subcircuit` builds (vkd/vkd.rs:362-612:
+    6 paddings, write-pp, one Append of 8 subcircuits, then Updates of 8 subcircuits each, final equality);
+    vm: vm/vm_constraints.rs:95-97."""
+    if not 0 <= idx < n:
+        raise IndexError("subcircuit index out of range: %d" % idx)
+    if family == "big-merkle":
+        if idx == 0:
+            return 0
+        if 1 <= idx < n // 2:
+            return 1
+        if n // 2 <= idx <= n - 3:
+            return n - 3
+        return idx                                   # n - 1 (padding), n - 2 (root)
+    if family == "vm":
+        return 0 if idx == 0 else 1
+    if family == "vkd":
+        if idx < 6:
+            return 0                                 # "padding"
+        if idx == 6:
+            return 6                                 # "write pp"
+        if idx == n - 1:
+            return n - 1                             # "equality"
+        u, k = divmod(idx - 7, 8)
+        if u == 0:                                   # the Append: 7 = hash leaf + get index + compute path,
+            return {0: 7, 3: 10}.get(k, 8)           # 10 = compute path + equality, the rest plain compute path
+        return 19 if k == 4 else 8                   # Updates: 5th = equality + hash leaf + compute path
+    raise KeyError(family)
 
 
 class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
@@ -317,6 +378,16 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
         return FrCodec(self.curve).enc(z[self.N_INST:self.N_INST + self.n0])
 
 
-def make_config(curve, name):
+def make_config(curve, name, class_rep=None):
+    """The synthetic subcircuit class of a BASELINE config.  `class_rep` (a representative subcircuit index from
+    `unique_subcircuits`) selects which of the config's proving-key classes: same size, different matrices
+    (class seed = base seed + representative index); None = the first class."""
     c = CONFIGS[name]
-    return SyntheticSubcircuit(curve, c["n_c"], c["n_free"], c["n0"])
+    seed = 0x48454B41544F4E31 + (0 if class_rep is None else int(class_rep))
+    return SyntheticSubcircuit(curve, c["n_c"], c["n_free"], c["n0"], class_seed=seed)
+
+
+def config_classes(name):
+    """(family, n_subcircuits, [class representatives]) of a BASELINE config."""
+    family, n = FAMILIES[name]
+    return family, n, unique_subcircuits(family, n)

@@ -133,3 +133,30 @@ def test_response_records_round_trip():
     b1 = Stage1Response.from_record(rec, g1, g2)
     assert b1.subcircuit_idx == 9 and b1.proof.ds[0].tobytes() == p.ds[0].tobytes()
     assert list(shard_range(512, 8, 7)) == list(range(448, 512))
+
+
+def test_class_maps_follow_the_reference_layouts():
+    """index -> proving-key class: tree_hash_circuit.rs:192-216, vkd_constraints.rs:199-214 (layout of
+    vkd.rs:362-612), vm_constraints.rs:91-97."""
+    from hekaton_system_amd.workload import (FAMILIES, config_classes, representative_subcircuit,
+                                             unique_subcircuits)
+    for name in FAMILIES:
+        fam, n, reps = config_classes(name)
+        for r in reps:
+            assert representative_subcircuit(fam, n, r) == r        # a representative represents itself
+        assert {representative_subcircuit(fam, n, i) for i in range(n)} == set(reps)
+    assert unique_subcircuits("big-merkle", 64) == [0, 1, 63, 62, 61]
+    bm = [representative_subcircuit("big-merkle", 64, i) for i in range(64)]
+    assert bm[0] == 0 and bm[1:32] == [1] * 31 and bm[32:62] == [61] * 30 and bm[62:] == [62, 63]
+    vk = [representative_subcircuit("vkd", 256, i) for i in range(256)]
+    assert vk[:7] == [0] * 6 + [6] and vk[7:15] == [7, 8, 8, 10, 8, 8, 8, 8]
+    assert vk[15:23] == [8, 8, 8, 8, 19, 8, 8, 8] and vk[255] == 255 and vk[19] == 19
+    assert len(unique_subcircuits("vkd", 256)) == 7
+    vm = [representative_subcircuit("vm", 1024, i) for i in range(1024)]
+    assert vm[0] == 0 and set(vm[1:]) == {1}
+    import pytest
+    with pytest.raises(IndexError):
+        representative_subcircuit("big-merkle", 64, 64)
+    a = make_config("bn254", "tiny", 0)
+    b = make_config("bn254", "tiny", 1)
+    assert (a.cols != b.cols).any()                                 # classes differ in their matrices

@@ -60,9 +60,9 @@ def _trapdoor_check(cname, circ, td, z, h, comms, kappas, r_, s_, proof):
     assert lhs == rhs, "Groth16 equation"
 
 
-def _run_config(ctx, cname, name, check_oracle_prove):
+def _run_config(ctx, cname, name, check_oracle_prove, check_oracle_commit=False, class_rep=None):
     fc = FrCodec(cname)
-    circ = make_config(cname, name)
+    circ = make_config(cname, name, class_rep)
     t0 = time.time()
     pk, td = generate_parameters(circ, cname, SeededRng(b"HEKATON1" * 4), ctx)
     dpk = pk.upload(ctx)
@@ -84,11 +84,12 @@ def _run_config(ctx, cname, name, check_oracle_prove):
     h = fc.dec(h_o)
     assert h[-1] == 0
     _trapdoor_check(cname, circ, td, z_ints, h, [com], [kappa], r_, s_, (a, b, c))
-    if check_oracle_prove:
+    if check_oracle_prove or check_oracle_commit:
         view = co.pk_view(a_g=pk.a_g, b_g=pk.b_g, b_h=pk.b_h, h_g=pk.h_g, ck_stages=pk.ck.deltas_abc_g,
                           deltas_g=pk.deltas_g, last_delta_h=pk.vk.last_delta_h, alpha_g=pk.vk.alpha_g,
                           beta_g=pk.beta_g, beta_h=pk.vk.beta_h)
         assert np.array_equal(co.commit(view, 0, w0, fc.enc1(kappa)), com)
+    if check_oracle_prove:
         oa, ob, oc = co.prove(view, A, B, C, circ.N_INST, circ.n_c, zb, fc.enc1(r_), fc.enc1(s_), fc.enc([kappa]))
         assert np.array_equal(oa, a) and np.array_equal(ob, b) and np.array_equal(oc, c)
     zdev.free(); dpk.free()
@@ -103,6 +104,26 @@ def test_config1_big_merkle_64x32_full_size_properties(ctx_bn254):
     """BASELINE configs[1] shape (m = 2^21, n_v ~ 1.3e6): proof valid under the trapdoor, witness map
     bit-exact vs the CPU oracle."""
     _run_config(ctx_bn254, "bn254", "big-merkle-64x32", check_oracle_prove=False)
+
+
+def test_config2_big_merkle_512x64_full_size_properties(ctx_bn254):
+    """BASELINE configs[2] shape (m = 2^22, n_v ~ 2.6e6; one GPU's share of the 8-GPU job proves exactly this
+    subcircuit shape): witness map bit-exact vs the CPU oracle, commit + proof valid under the trapdoor."""
+    _run_config(ctx_bn254, "bn254", "big-merkle-512x64", check_oracle_prove=False)
+
+
+def test_config3_vkd_256_bit_exact_vs_cpu_oracle(ctx_bn254):
+    """BASELINE configs[3] (vkd, 256 subcircuits, 7 proving-key classes).  The per-subcircuit size is the flagged
+    placeholder of SURVEY.md §8 (m = 2^17, n0 = 8 192 portal witnesses): commit (an 8 192-term MSM) and proof
+    bit-exact vs the C++ oracle and valid under the trapdoor, on the most common class ("compute path", 8)."""
+    _run_config(ctx_bn254, "bn254", "vkd-256", check_oracle_prove=True, class_rep=8)
+
+
+def test_config4_vm_1024x1024_commit_bit_exact_and_proof_valid(ctx_bn254):
+    """BASELINE configs[4] shape (m = 2^20, n_v ~ 1.7e6, 217 280 stage-0 witnesses): the only config whose
+    hk_commit is a large MSM (committer.rs:89) - bit-exact vs `COracle.commit`; witness map bit-exact; proof and
+    commitment valid under the trapdoor."""
+    _run_config(ctx_bn254, "bn254", "vm-1024x1024", check_oracle_prove=False, check_oracle_commit=True, class_rep=1)
 
 
 @pytest.mark.parametrize("group,n,dense", [(1, 1 << 16, True), (1, 1 << 16, False), (2, 1 << 13, True),
