@@ -72,9 +72,13 @@ HK_HD XYZZ<F> ec_dbl(const XYZZ<F>& p) {
     return r;
 }
 
-// NOTE: keep the P == Q corner of ec_add out of line.  With it inlined, the (already out-of-line)
-// ec_add_ni of the 12-limb BLS12-381 fields faulted on the GPU ("memory access fault" in the private
-// aperture, k_msm_bucket_reduce) although the same source is fine for 8-limb fields — see DESIGN.md.
+// The P == Q corner of ec_add stays OUT of line, for a reason that is a toolchain limit, not taste: with it inlined
+// the out-of-line ec_add_ni of a 12-limb field becomes a LEAF function of 188 KB, more than the +-128 KiB reach of
+// s_cbranch, and hipcc (ROCm 7.2) then materialises its long jumps as `s_getpc_b64 s[30:31]` ... `s_setpc_b64 s[30:31]`
+// - through the function's own return address, which a leaf never saves.  The `if (b.is_inf()) return a;` path of
+// that build "returned" into itself and faulted on a flat load from {lo = sret+48, hi = sret+64} = 0x280_0000_0xxx:
+// the two GPU faults of round 1 (profiles/r02_bls_fault_root_cause.txt).  `make` fails the build when any
+// device function outgrows the branch reach or such a long branch appears (tools/kernel_meta.py --check).
 template <class F>
 HK_RARE XYZZ<F> ec_dbl_rare(const XYZZ<F>& p) { return ec_dbl(p); }
 
@@ -93,9 +97,9 @@ HK_HD XYZZ<F> ec_madd(const XYZZ<F>& a, const Affine<F>& q) {
     XYZZ<F> o;
     if (p.is_zero()) {
         if (!r.is_zero()) return XYZZ<F>::inf();
-        // 12-limb coordinate fields keep the out-of-line form by default: their G2 kernels are at the edge of
-        // what hipcc/gfx950 handles (see the note at ec_dbl_rare and DESIGN.md); the G1 accumulate loop asks for the
-        // inline form explicitly (145 VGPRs and no scratch instead of 187 VGPRs and 304 B of scratch per lane)
+        // 12-limb coordinate fields keep the out-of-line form by default (code size: see the note at ec_dbl_rare);
+        // the G1 accumulate loop asks for the inline form explicitly (145 VGPRs and no scratch instead of 187 VGPRs
+        // and 304 B of scratch per lane)
         if constexpr (!INLINE_CORNER) return ec_dbl_affine(q);
         // doubling of the affine point ("mdbl-2008-s-1", a = 0)
         F u = F::dbl(q.y);

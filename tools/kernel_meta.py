@@ -4,8 +4,13 @@ VGPRs / AGPRs, scratch bytes per lane (.private_segment_fixed_size), dynamic-sta
 
     python tools/kernel_meta.py [file ...] [--check]   # default: hekaton_system_amd/lib/libhekaton.so
 
---check enforces the bounds DESIGN.md §"BLS12-381 fault" establishes (the build runs it, see csrc/Makefile):
-no kernel may use a dynamic stack, and no kernel may need more private memory per lane than SCRATCH_LIMIT_BYTES.
+--check enforces the bounds DESIGN.md §3a ("The BLS12-381 GPU fault of round 1") establishes; the build runs it
+(csrc/Makefile, `__graft_entry__.build()`):
+  1. no device FUNCTION (non-kernel symbol) may be larger than the reach of `s_cbranch` (+-32767 dwords = 131 068 B):
+     above it hipcc's branch relaxation emits long jumps through `s_getpc_b64 s[30:31]` / `s_setpc_b64 s[30:31]` in
+     leaf functions, i.e. through the function's own return address, which a leaf never saves;
+  2. no `s_getpc_b64 s[30:31]` anywhere (the direct signature of that miscompile);
+  3. no kernel may use a dynamic stack or need more private memory per lane than SCRATCH_LIMIT_BYTES.
 """
 import os
 import re
@@ -21,6 +26,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # stack) a dispatch takes the slow "use once" path.  4 KB per lane keeps every kernel far from the flat-scratch
 # addressing limits as well (13-bit immediate offsets hold +-4 KB).
 SCRATCH_LIMIT_BYTES = 4096
+BRANCH_REACH_BYTES = 32767 * 4      # s_cbranch_*: signed 16-bit dword offset
+
+
+def function_sizes(co):
+    """(size, is_kernel, mangled name) of every function symbol of a code object."""
+    out = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "--wide", co], text=True, capture_output=True,
+                         check=True).stdout
+    funcs, kds = [], set()
+    for line in out.splitlines():
+        f = line.split()
+        if len(f) >= 8 and f[3] == "OBJECT" and f[7].endswith(".kd"):
+            kds.add(f[7][:-3])
+    for line in out.splitlines():
+        f = line.split()
+        if len(f) >= 8 and f[3] == "FUNC":
+            funcs.append((int(f[2]), f[7] in kds, f[7]))
+    return funcs
+
+
+def retaddr_long_branches(co):
+    """Number of `s_getpc_b64 s[30:31]` in the code object's disassembly."""
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True,
+                         capture_output=True, check=True).stdout
+    return dis.count("s_getpc_b64 s[30:31]")
 
 
 def code_objects(path):
@@ -59,12 +88,15 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     check = "--check" in sys.argv
     files = args or [os.path.join(ROOT, "hekaton_system_amd", "lib", "libhekaton.so")]
-    rows = []
+    rows, funcs, n_getpc = [], [], 0
     for f in files:
         tmp, cos = code_objects(f)
         try:
             for co in cos:
                 rows += kernels_of(co)
+                funcs += function_sizes(co)
+                if check:
+                    n_getpc += retaddr_long_branches(co)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     dm = demangle([r["symbol"] for r in rows])
@@ -80,14 +112,27 @@ def main():
                                                          "YES" if r["dyn_stack"] else "-", name[:150]))
         if r["dyn_stack"] or r["scratch"] > SCRATCH_LIMIT_BYTES:
             bad.append(name)
+    fdm = demangle([f[2] for f in funcs]) if funcs else {}
+    big = sorted({(sz, k, fdm[n]) for sz, k, n in funcs if sz > BRANCH_REACH_BYTES}, reverse=True)
+    largest = max(funcs) if funcs else (0, False, "")
+    print("\nlargest function: %d B (%s); s_cbranch reach %d B; %d function(s) above it" % (
+        largest[0], fdm.get(largest[2], "")[:80], BRANCH_REACH_BYTES, len(big)))
+    for sz, k, n in big:
+        print("  %7d B  %s  %s" % (sz, "kernel  " if k else "FUNCTION", n[:150]))
+        if not k:
+            bad.append("device function larger than the s_cbranch reach (%d B): %s" % (sz, n))
+    if check and n_getpc:
+        bad.append("%d long branch(es) through the return-address pair s[30:31]" % n_getpc)
     if check and bad:
-        print("\nkernel_meta --check FAILED (dynamic stack or scratch > %d B per lane):" % SCRATCH_LIMIT_BYTES, file=sys.stderr)
+        print("\nkernel_meta --check FAILED (dynamic stack, scratch > %d B per lane, oversized device function or "
+              "s[30:31] long branch):" % SCRATCH_LIMIT_BYTES, file=sys.stderr)
         for b in bad:
             print("  " + b[:200], file=sys.stderr)
         sys.exit(1)
     if check:
-        print("\nkernel_meta --check ok: %d kernels, no dynamic stack, max scratch %d B per lane (limit %d)" % (
-            len(rows), max(r["scratch"] for r in rows), SCRATCH_LIMIT_BYTES))
+        print("kernel_meta --check ok: %d kernels, no dynamic stack, max scratch %d B per lane (limit %d), no device "
+              "function above the s_cbranch reach, no s[30:31] long branch" % (
+                  len(rows), max(r["scratch"] for r in rows), SCRATCH_LIMIT_BYTES))
 
 
 if __name__ == "__main__":
