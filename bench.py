@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — subcircuit Groth16 proofs/sec on N MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic subcircuits per GPU: for every
-subcircuit one stage-0 commit (hk_commit) and one stage-1 prove (hk_prove), exactly the unit of work
-`process_stage0_request` / `process_stage1_request` do in the reference
-(distributed-prover/src/worker.rs:91-146,150-195).  Subcircuits are sharded contiguously over ranks
-(mpi-snark/src/bin/node.rs:471-472,490-493); there is no data-path collective (weak scaling: every
-GPU proves `--subcircuits` of them per step).  Inputs (proving key with shift tables, matrices,
-assignments) are resident in HBM before the timed region; outputs are 3 affine points per proof.
+A "step" is one job of the reference's `node work` flow over one batch of synthetic subcircuits per GPU
+(mpi-snark/src/bin/node.rs:461-621), without the coordinator's own work:
+
+    round 1  every subcircuit of the rank's shard: stage-0 commitment   (worker.rs:91-146  -> hk_commit)
+             gather the 104-byte Stage0Response records of all ranks    (node.rs:500-506)
+    round 2  every subcircuit of the rank's shard: stage-1 proof        (worker.rs:150-195 -> hk_prove)
+             gather the 328-byte Stage1Response records of all ranks    (node.rs:526-533)
+
+Subcircuits are sharded contiguously over ranks (node.rs:471-472,490-493); the two gathers are the only
+exchange steps (torch.distributed all_gather: RCCL on the GPUs, gloo for the CPU rehearsal).  Every rank holds
+the proving-key classes its shard needs, chosen per subcircuit index by the circuit family's
+`representative_subcircuit` (big-merkle: tree_hash_circuit.rs:192-216 - five classes).  Weak scaling: every GPU
+proves `--subcircuits` subcircuits per step (BASELINE configs[1] = 64 on one GPU, configs[2] = 512 on eight).
+Inputs (keys with shift tables, matrices, assignments) are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus 4                      # starts 4 rank processes itself (rank r -> device r)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --device 0           # rehearsal: 2 ranks on ONE GPU (gloo gathers)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -22,9 +34,10 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# measured ceilings of the field multiply loop (tools/ubench.hip, profiles/r01_ubench_asm_addsub.txt): G products/s
+VALU_PRODUCT_CEILING = {"bn254": 134.0, "bls12_381": 63.0}
+VMAD_RATE_TOPS = 24.7      # chip-wide v_mad_u64_u32 issue rate (profiles/r01_ubench_instruction_rates.txt)
 
 
 def log(*a):
@@ -40,22 +53,63 @@ def parse():
                     help="workload (hekaton_system_amd/workload.py CONFIGS); default = BASELINE configs[1]")
     ap.add_argument("--curve", default="bn254", help="bn254 is what the reference instantiates (SURVEY F1)")
     ap.add_argument("--subcircuits", type=int, default=64,
-                    help="subcircuits per GPU per step (default: the 64 subcircuits of BASELINE configs[1], "
-                         "big-merkle N=64; a step is that whole batch, proved 8 at a time)")
+                    help="subcircuits per GPU per step (default: the 64 subcircuits of BASELINE configs[1])")
     ap.add_argument("--threads", type=int, default=8, help="host threads (= GPU lanes) proving concurrently")
-    ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments cycled through")
+    ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments per proving-key class")
+    ap.add_argument("--single-class", action="store_true",
+                    help="prove every subcircuit against ONE proving-key class (debug; the default holds every class "
+                         "of the rank's shard resident and picks by the reference's index -> class map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the BLS12-381 secondary measurement (N = 1 only)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-timing checks of the timed proofs")
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand every assignment over from host memory (PCIe-inclusive rate; never the headline value)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--backend", default="auto",
+                    help="torch.distributed backend for N > 1: nccl (= RCCL), gloo, or auto (nccl unless --device "
+                         "puts several ranks on one GPU)")
     ap.add_argument("--device", type=int, default=None,
-                    help="force a device index (rehearsing N > 1 ranks on a 1-GPU box with --backend gloo)")
+                    help="force a device index for every rank (rehearsing N > 1 ranks on a 1-GPU box)")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------- self-launch
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (rank r -> device r) BEFORE
+    anything in this process touches HIP, forward their output, return the worst exit code.  The parent never
+    initialises the GPU (a process that has must not exec or fork workers on this pool)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:              # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.2)
+    except KeyboardInterrupt:
+        for p in procs:
+            p.terminate()
+        rc = 130
+    return rc
+
+
+# ------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(args, circ, pk_host, fc):
-    """The CPU restatement of the ark-ec/ark-poly path (oracle/c, kind "port") timed on this box's
-    host cores over a bounded sample of the same workload: three subcircuits, commit + prove each."""
+    """The CPU restatement of the ark-ec/ark-poly path (oracle/c, kind "port") on this box's host cores, run the
+    way the reference fills a node: floor(cores / 32) proofs in flight, 32 threads each (node.rs:745-795 with
+    slurm_scripts/run_single_bench:5-7).  Also the latency of one proof alone with 32 threads."""
     import shutil
     import tempfile
     from oracle import c_oracle
@@ -66,178 +120,387 @@ def cpu_baseline(args, circ, pk_host, fc):
         except Exception as e:       # noqa: BLE001
             log("native oracle build failed, using prebuilt:", e)
     co = c_oracle.COracle(args.curve, lib_path=lib)
-    cores = co.threads()
+    cores = os.cpu_count() or 1
+    per_task = min(32, cores)
+    co.set_threads(per_task)
+    conc = max(1, cores // 32)
     view = co.pk_view(**pk_host["points"])
     A, B, C = pk_host["matrices"]
     kap = fc.enc([7])
-    n_sample = 3                                   # ~15 s of CPU work on the GPU box's host cores
     inputs = []
-    for seed in range(1, n_sample + 1):
+    for seed in range(1, min(conc, 4) + 1):
         circ.set_witness_seed(seed)
         inputs.append((circ.full_assignment_bytes(), circ.stage0_witness_bytes()))
-    t0 = time.time()
-    for z, w0 in inputs:
+
+    def one(i):
+        z, w0 = inputs[i % len(inputs)]
         co.commit(view, 0, w0, kap)
         co.prove(view, A, B, C, circ.N_INST, circ.n_c, z, fc.enc1(11), fc.enc1(13), kap)
+
+    t0 = time.time()
+    one(0)
+    lat = time.time() - t0
+    # bounded sample: enough rounds of `conc` concurrent proofs for ~15-25 s of wall clock
+    rounds = max(1, min(3, int(20.0 / max(lat, 1e-3))))
+    n = conc * rounds
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=conc) as pool:
+        list(pool.map(one, range(n)))
     dt = time.time() - t0
-    return {"value": n_sample / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": "%d subcircuits (1 commit + 1 prove each) of %s, %.1f s" % (n_sample, args.config, dt)}
+    return {"value": n / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "concurrent_proofs": conc, "threads_per_proof": per_task, "single_proof_latency_s": lat,
+            "sample": "%d subcircuits (1 commit + 1 prove each) of %s, %d in flight x %d threads, %.1f s; one proof "
+                      "alone: %.1f s" % (n, args.config, conc, per_task, dt, lat)}
+
+
+# ------------------------------------------------------------------------------------------- one measured job
+class Job:
+    """Keys, assignments and the step function of one (curve, config) on one rank."""
+
+    def __init__(self, args, curve, rank, world, dev, backend, single_class=False, keep_host=False,
+                 witnesses=None):
+        from hekaton_system_amd import capi
+        from hekaton_system_amd.cp_groth16 import FrCodec, SeededRng, generate_parameters
+        from hekaton_system_amd.workload import config_classes, make_config, representative_subcircuit
+        from hekaton_system_amd.worker import shard_range
+        self.args, self.curve, self.rank, self.world, self.backend = args, curve, rank, world, backend
+        self.capi = capi
+        self.ctx = capi.Context(curve, dev)
+        self.fc = FrCodec(curve)
+        family, _n_default, _reps = config_classes(args.config)
+        self.family = family
+        S = args.subcircuits
+        self.n_total = S * world
+        self.shard = list(shard_range(self.n_total, world, rank))
+        if single_class:
+            self.class_of = {i: 1 for i in self.shard}
+        else:
+            self.class_of = {i: representative_subcircuit(family, self.n_total, i) for i in self.shard}
+        need = sorted(set(self.class_of.values()))
+        count = {rep: sum(1 for i in self.shard if self.class_of[i] == rep) for rep in need}
+        self.main_class = max(need, key=lambda rep: (count[rep], -rep))      # the shard's most common class
+        keep_host_class = self.main_class if keep_host else None
+        nw = witnesses or args.witnesses
+        self.classes = {}
+        t0 = time.time()
+        for rep in need:
+            circ = make_config(curve, args.config, rep)
+            seed = hashlib.sha256(b"HEKATON1 class %d" % rep).digest()
+            keep_host = keep_host_class is not None and rep == keep_host_class
+            pk, td = generate_parameters(circ, curve, SeededRng(seed), self.ctx, keep_on_device=not keep_host)
+            dpk = pk.upload(self.ctx)
+            host = None
+            if keep_host:
+                host = {"points": dict(a_g=pk.a_g, b_g=pk.b_g, b_h=pk.b_h, h_g=pk.h_g, ck_stages=pk.ck.deltas_abc_g,
+                                       deltas_g=pk.deltas_g, last_delta_h=pk.vk.last_delta_h, alpha_g=pk.vk.alpha_g,
+                                       beta_g=pk.beta_g, beta_h=pk.vk.beta_h),
+                        "matrices": pk.matrices}
+            else:
+                for b in (pk.a_g, pk.b_g, pk.b_h, pk.h_g):
+                    if isinstance(b, capi.DeviceBuffer):
+                        b.free()
+            members = [i for i in self.shard if self.class_of[i] == rep]
+            k = min(nw, len(members))
+            zs, w0s, seeds = [], [], []
+            for j in range(k):
+                ws = 1000 * rep + j + 1
+                circ.set_witness_seed(ws)
+                zb, wb = circ.full_assignment_bytes(), circ.stage0_witness_bytes()
+                zs.append(zb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, zb))
+                w0s.append(wb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, wb))
+                seeds.append(ws)
+            self.classes[rep] = dict(circ=circ, pk=pk, td=td, dpk=dpk, host=host, zs=zs, w0s=w0s, seeds=seeds,
+                                     members=members, matrices=pk.matrices)
+            log("rank %d: %s class %d (%d subcircuits of this shard): key + %d assignments resident, %.1f s" % (
+                rank, curve, rep, len(members), k, time.time() - t0))
+        self.circ = self.classes[self.main_class]["circ"]
+        # which assignment a subcircuit uses: its position within its class, cycled
+        self.assign_of = {}
+        for rep, c in self.classes.items():
+            for pos, i in enumerate(c["members"]):
+                self.assign_of[i] = pos % len(c["zs"])
+        # fixed per-subcircuit randomness: com_seed (worker.rs:129) and the prover's r, s (prover.rs:28-29) derive from
+        # the index only, so a subcircuit's responses are byte-identical in every step (checked after the timed region)
+        p_mod = self.fc.r
+        from hekaton_system_amd.chacha import ChaCha12Rng
+        self.rand = {}
+        for i in self.shard:
+            com_seed = hashlib.sha256(b"com_seed %d" % i).digest()
+            kappa = ChaCha12Rng(com_seed).fr(p_mod)                    # mpi-snark/src/worker.rs:63-66
+            rr = int.from_bytes(hashlib.sha256(b"r %d" % i).digest(), "little") % p_mod
+            ss = int.from_bytes(hashlib.sha256(b"s %d" % i).digest(), "little") % p_mod
+            self.rand[i] = dict(com_seed=com_seed, kappa=kappa, r=rr, s=ss, kappa_b=self.fc.enc1(kappa),
+                                r_b=self.fc.enc1(rr), s_b=self.fc.enc1(ss))
+        self.ctx.set_profiling(True)
+        self.pool = ThreadPoolExecutor(max_workers=args.threads)
+        self.accum_ms, self.accum_n, self.accum_h, self.phase = [], [], [], {}
+        self.gather_s = 0.0
+        self.last_records = None
+        self.prev_records = None
+
+    # -- the two rounds of one subcircuit ----------------------------------------------------------------
+    def _stage0(self, i):
+        from hekaton_system_amd.worker import Stage0Response
+        c = self.classes[self.class_of[i]]
+        k = self.assign_of[i]
+        rnd = self.rand[i]
+        com = c["dpk"].commit(0, c["w0s"][k], rnd["kappa_b"], n=c["circ"].n0)
+        t = self.ctx.last_timings()
+        return Stage0Response(i, com, rnd["com_seed"]).to_record(), t
+
+    def _stage1(self, i_com):
+        from hekaton_system_amd.cp_groth16 import Proof
+        from hekaton_system_amd.worker import Stage1Response
+        i, com = i_com
+        c = self.classes[self.class_of[i]]
+        k = self.assign_of[i]
+        rnd = self.rand[i]
+        a, b, cc = c["dpk"].prove(c["zs"][k], rnd["r_b"], rnd["s_b"], rnd["kappa_b"], n_v=c["circ"].n_v)
+        t = self.ctx.last_timings()
+        return Stage1Response(i, Proof(a, b, cc, [com])).to_record(), t
+
+    def _gather(self, records):
+        from hekaton_system_amd.worker import gather_records
+        t0 = time.time()
+        out = gather_records(records, self.world, "cuda" if (self.world > 1 and self.backend == "nccl") else "cpu")
+        self.gather_s += time.time() - t0
+        return out
+
+    def step(self, record):
+        g1b = self.ctx.g1_bytes
+        r0 = list(self.pool.map(self._stage0, self.shard))
+        all0 = self._gather([r for r, _ in r0])                           # node.rs:500-506
+        assert len(all0) == self.n_total
+        coms = [r[8:8 + g1b] for r, _ in r0]
+        r1 = list(self.pool.map(self._stage1, zip(self.shard, coms)))
+        all1 = self._gather([r for r, _ in r1])                           # node.rs:526-533
+        assert len(all1) == self.n_total
+        if record:
+            for (_, tc), (_, t) in zip(r0, r1):
+                self.accum_ms.append(t["accum_kernel_ms"] + tc["accum_kernel_ms"])
+                self.accum_n.append(t["accum_kernel_launches"] + tc["accum_kernel_launches"])
+                self.accum_h.append(t["accum_h_ms"])
+                for key, v in t.items():
+                    self.phase[key] = self.phase.get(key, 0.0) + v
+        self.prev_records, self.last_records = self.last_records, (all0, all1)
+        return all0, all1
+
+    # -- post-timing checks of the timed proofs (never inside the timed region) -------------------------
+    def verify_last_step(self):
+        """(i) a subcircuit's records are byte-identical in the last two timed steps; (ii) subcircuits with distinct
+        assignments / randomness have distinct proofs; (iii) one timed proof of this rank passes the trapdoor form of
+        the Groth16 verifier equation (cp_groth16.trapdoor_verify), with h recomputed by hk_witness_map."""
+        from hekaton_system_amd.cp_groth16 import trapdoor_verify
+        import numpy as np
+        out = {}
+        all0, all1 = self.last_records
+        if self.prev_records is not None:
+            p0, p1 = self.prev_records
+            assert np.array_equal(all0, p0) and np.array_equal(all1, p1), "responses changed between timed steps"
+            out["repeat_identical"] = True
+        proofs = {bytes(r[8:]) for r in all1}
+        assert len(proofs) == self.n_total, "distinct subcircuits gave identical proofs"
+        out["distinct_proofs"] = len(proofs)
+        idx = [int.from_bytes(bytes(r[:8]), "little") for r in all1]
+        assert idx == list(range(self.n_total)), "gathered records are not in subcircuit order"
+        # trapdoor check of the LAST subcircuit of this rank's shard, from the gathered record
+        i = self.shard[-1]
+        c = self.classes[self.class_of[i]]
+        circ, td = c["circ"], c["td"]
+        circ.set_witness_seed(c["seeds"][self.assign_of[i]])
+        z_ints = circ.assignment_ints()
+        A, B, C = c["matrices"]
+        h_b, m = self.ctx.witness_map(A, B, C, circ.N_INST, circ.n_c, c["zs"][self.assign_of[i]], n_v=circ.n_v)
+        h = self.fc.dec(h_b)
+        rec = all1[i]
+        g1b, g2b = self.ctx.g1_bytes, self.ctx.g2_bytes
+        a, b, cc = rec[8:8 + g1b], rec[8 + g1b:8 + g1b + g2b], rec[8 + g1b + g2b:8 + 2 * g1b + g2b]
+        com = all0[i][8:8 + g1b]
+        rnd = self.rand[i]
+        trapdoor_verify(self.ctx, self.curve, td, circ.N_INST, td.stage_ranges, z_ints, h, [com], [rnd["kappa"]],
+                        rnd["r"], rnd["s"], (a, b, cc))
+        out["trapdoor_verified_subcircuit"] = i
+        return out
+
+    def close(self):
+        self.pool.shutdown()
+        for c in self.classes.values():
+            for b in c["zs"] + c["w0s"]:
+                if isinstance(b, self.capi.DeviceBuffer):
+                    b.free()
+            c["dpk"].free()
+        self.ctx.close()
+
+
+def timed_run(job, steps, warmup, barrier):
+    for _ in range(warmup):
+        job.step(False)
+    job.gather_s = 0.0
+    barrier()
+    t0 = time.time()
+    for _ in range(steps):
+        job.step(True)
+    job.ctx.sync()
+    barrier()
+    return time.time() - t0
+
+
+def roofline_of(job, curve):
+    """Dominant kernel = k_msm_accum0<Fq> (bucket accumulation), launched 5 times per subcircuit: H query (m-1 dense
+    terms), A / B1 / L queries (n_v-1, n_v-1, n1 terms) and the stage-0 commitment.  Algorithmic bytes per launch =
+    terms * (32 + S1) (SURVEY.md §8d "MSM-G1 = n*(32+S1)"), averaged over the same launches whose durations are
+    averaged - the population rocprofv3 --stats averages."""
+    import numpy as np
+    circ, ctx = job.circ, job.ctx
+    m = 1
+    while m < circ.n_c + circ.N_INST:
+        m *= 2
+    g1 = ctx.g1_bytes
+    n1 = circ.n_v - circ.N_INST - circ.n0
+    fq_limbs = ctx.fq_bytes // 4
+    nwin = (ctx.fr_bytes * 8 + 1 + 15) // 16 if curve == "bls12_381" else 16      # ceil((bits+2)/16): 16 / 17
+    terms = [m - 1, circ.n_v - 1, circ.n_v - 1, n1, circ.n0]
+    alg_bytes = sum(terms) * (32 + g1) / len(terms)
+    avg_ms = float(np.sum(job.accum_ms) / max(1, np.sum(job.accum_n))) if job.accum_ms else float("nan")
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    h_ms = float(np.mean(job.accum_h)) if job.accum_h else float("nan")
+    traffic = None
+    try:      # HBM traffic of the same kernel from separate rocprofv3 --pmc passes (cannot be read live)
+        with open(os.path.join(ROOT, "profiles", "pmc_accum0.json")) as f:
+            pmc = json.load(f)
+        key = "%s/%s" % (job.args.config, curve)
+        if key in pmc:
+            traffic = (pmc[key]["FETCH_SIZE_KiB_avg"] + pmc[key]["WRITE_SIZE_KiB_avg"]) * 1024.0
+    except Exception:       # noqa: BLE001
+        pass
+    prods = (m - 1) * nwin * 10 / (h_ms * 1e-3) / 1e9
+    mad_only = VMAD_RATE_TOPS * 1e3 / (2 * (fq_limbs ** 2))
+    return m, {
+        "bound": "hbm",
+        "kernel": "k_msm_accum0<Fp<%s>> (bucket accumulation; avg over its 5 launches per subcircuit)" % (
+            "Bn254FqP" if curve == "bn254" else "Bls381FqP"),
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+        "h_query_launch": {"alg_bytes": (m - 1) * (32 + g1), "avg_ms": h_ms,
+                           "achieved": (m - 1) * (32 + g1) / (h_ms * 1e-3) / 1e9},
+        # the bound that actually binds: integer VALU issue.  One mixed add = 10 Montgomery products; peak = the
+        # MEASURED ceiling of the whole product loop (mads + carries + moves, tools/ubench.hip), with the
+        # v_mad_u64_u32-only issue limit (24.7 Top/s / 2 N^2 mads per product) kept beside it
+        "valu": {"unit": "G field mults/s", "achieved": prods, "peak": VALU_PRODUCT_CEILING[curve],
+                 "frac": prods / VALU_PRODUCT_CEILING[curve], "peak_mad_only": mad_only,
+                 "frac_mad_only": prods / mad_only,
+                 "note": "H-query launch: (m-1) scalars x %d signed 16-bit digits x 10 products per mixed add" % nwin}}
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))                     # before any HIP call
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    from hekaton_system_amd import capi          # first: exports GPU_MAX_HW_QUEUES before anything initialises HIP
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or run without a launcher and let "
+                 "bench.py start the ranks itself)" % (args.gpus, world))
+    if os.environ.get("HK_BENCH_ECHO_RANK"):
+        log("rank %d of %d starting (pid %d)" % (rank, world, os.getpid()))
+    from hekaton_system_amd import capi          # noqa: F401  first: exports GPU_MAX_HW_QUEUES before HIP initialises
     import torch
     import torch.distributed as dist
     dev = local_rank if args.device is None else args.device
+    backend = args.backend
+    if backend == "auto":
+        backend = "gloo" if (args.device is not None and world > 1) else "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev)
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-    from hekaton_system_amd.cp_groth16 import FrCodec, SeededRng, generate_parameters
-    from hekaton_system_amd.workload import make_config
-
-    ctx = capi.Context(args.curve, dev)
-    fc = FrCodec(args.curve)
-    circ = make_config(args.curve, args.config)
-    log("rank %d: setup %s n_c=%d n_v=%d" % (rank, args.config, circ.n_c, circ.n_v))
-    t0 = time.time()
-    keep_host = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    pk, td = generate_parameters(circ, args.curve, SeededRng(b"HEKATON1" * 4), ctx, keep_on_device=not keep_host)
-    dpk = pk.upload(ctx)
-    pk_host = None
-    if keep_host:
-        pk_host = {"points": dict(a_g=pk.a_g, b_g=pk.b_g, b_h=pk.b_h, h_g=pk.h_g, ck_stages=pk.ck.deltas_abc_g,
-                                  deltas_g=pk.deltas_g, last_delta_h=pk.vk.last_delta_h, alpha_g=pk.vk.alpha_g,
-                                  beta_g=pk.beta_g, beta_h=pk.vk.beta_h),
-                   "matrices": pk.matrices}
-    else:
-        for b in (pk.a_g, pk.b_g, pk.b_h, pk.h_g):
-            if isinstance(b, capi.DeviceBuffer):
-                b.free()
-    log("rank %d: key generated + resident in %.1f s" % (rank, time.time() - t0))
-    # assignments resident in HBM
-    zs, w0s = [], []
-    for k in range(args.witnesses):
-        circ.set_witness_seed(1000 * rank + k + 1)
-        zb, wb = circ.full_assignment_bytes(), circ.stage0_witness_bytes()
-        zs.append(zb if args.host_inputs else capi.DeviceBuffer.from_host(ctx, zb))
-        w0s.append(wb if args.host_inputs else capi.DeviceBuffer.from_host(ctx, wb))
-    r_b, s_b, kap = fc.enc1(0x1234567), fc.enc1(0x7654321), fc.enc([0x5555])
-    ctx.set_profiling(True)
-    accum_ms, accum_n, accum_h, phase = [], [], [], {}
-
-    def one(i):
-        k = i % args.witnesses
-        dpk.commit(0, w0s[k], kap, n=circ.n0)
-        tc = ctx.last_timings()
-        out = dpk.prove(zs[k], r_b, s_b, kap, n_v=circ.n_v)
-        t = ctx.last_timings()
-        t["accum_kernel_ms"] += tc["accum_kernel_ms"]            # the commit's launch of the same kernel
-        t["accum_kernel_launches"] += tc["accum_kernel_launches"]
-        return out, t
-
-    pool = ThreadPoolExecutor(max_workers=args.threads)
-
-    def step(record):
-        res = list(pool.map(one, range(args.subcircuits)))
-        if record:
-            for _, t in res:
-                accum_ms.append(t["accum_kernel_ms"])
-                accum_n.append(t["accum_kernel_launches"])
-                accum_h.append(t["accum_h_ms"])
-                for key, v in t.items():
-                    phase[key] = phase.get(key, 0.0) + v
-        return res
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        log("rank %d/%d on device %d, %s backend sees %d ranks" % (rank, world, dev, backend, dist.get_world_size()))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.time()
-    for _ in range(args.steps):
-        last = step(True)
-    ctx.sync()
-    barrier()
-    dt = time.time() - t0
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    job = Job(args, args.curve, rank, world, dev, backend, single_class=args.single_class, keep_host=want_cpu)
+    circ = job.circ
+    dt_local = timed_run(job, args.steps, args.warmup, barrier)
+    dt = dt_local
+    per_rank = [args.subcircuits * args.steps / dt_local]
+    gather_ms = [job.gather_s / args.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        on = "cuda" if backend == "nccl" else "cpu"
+        tt = torch.tensor([dt_local], dtype=torch.float64, device=on)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        mine = torch.tensor([per_rank[0], gather_ms[0]], dtype=torch.float64, device=on)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x[0]) for x in allr]
+        gather_ms = [float(x[1]) for x in allr]
+    checks = None
+    if not args.no_verify:
+        t0 = time.time()
+        checks = job.verify_last_step()              # every rank checks its own shard; raises on failure
+        checks["seconds"] = time.time() - t0
+        log("rank %d: timed proofs verified: %s" % (rank, checks))
     proofs = world * args.subcircuits * args.steps
     if rank == 0:
-        m = 1
-        while m < circ.n_c + circ.N_INST:
-            m *= 2
-        g1 = ctx.g1_bytes
-        # dominant kernel = k_msm_accum0<Fq> (bucket accumulation).  It is launched 5 times per subcircuit:
-        # H query (m-1 dense terms), A / B1 / L queries (n_v-1, n_v-1, n1 terms) and the stage-0 commitment.
-        # Algorithmic bytes per launch = terms * (32 + S1)  (SURVEY.md §8d "MSM-G1 = n*(32+S1)"), averaged
-        # over the same launches whose durations are averaged — the population rocprofv3 --stats averages.
-        n1 = circ.n_v - circ.N_INST - circ.n0
-        fq_limbs = ctx.fq_bytes // 4
-        nwin = (ctx.fr_bytes * 8 + 1 + 15) // 16 if args.curve == "bls12_381" else 16      # ceil((bits+2)/16): 16 / 17
-        terms = [m - 1, circ.n_v - 1, circ.n_v - 1, n1, circ.n0]
-        alg_bytes = sum(terms) * (32 + g1) / len(terms)
-        avg_ms = float(np.sum(accum_ms) / max(1, np.sum(accum_n))) if accum_ms else float("nan")
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        h_ms = float(np.mean(accum_h)) if accum_h else float("nan")
-        nprov = max(1, len(accum_ms))
-        # HBM traffic of the same kernel from rocprofv3 PMC passes (profiles/, collected offline with
-        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this command; cannot be read live)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_accum0.json")) as f:
-                pmc = json.load(f)
-            if args.config == "big-merkle-64x32" and args.curve == "bn254":
-                traffic = (pmc["FETCH_SIZE_KiB_avg"] + pmc["WRITE_SIZE_KiB_avg"]) * 1024.0
-        except Exception:       # noqa: BLE001
-            pass
+        m, roof = roofline_of(job, args.curve)
+        nprov = max(1, len(job.accum_ms))
         out = {
             "metric": "subcircuit Groth16 proofs/sec (whole node), big-merkle",
             "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (Montgomery mod-p integers)",
-            "data": "synthetic (SHA-like 85%% small / 15%% full-width witnesses, genuine Groth16 SRS from a "
-                    "seeded trapdoor; %d distinct assignments cycled%s)" % (
+            "data": "synthetic (SHA-like 85%% small / 15%% full-width witnesses, genuine Groth16 SRS from a seeded "
+                    "trapdoor per proving-key class; up to %d distinct assignments per class%s)" % (
                         args.witnesses, "; assignments copied from pageable host memory per proof" if args.host_inputs else ""),
             "config": {"workload": args.config, "curve": args.curve, "subcircuits_per_gpu_per_step": args.subcircuits,
-                       "n_constraints": circ.n_c, "n_variables": circ.n_v, "domain": m,
-                       "host_threads_per_gpu": args.threads, "sharding": "subcircuits/%d per rank" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accum0<Fp<%s>> (bucket accumulation; avg over its 5 launches per subcircuit)" % ("Bn254FqP" if args.curve == "bn254" else "Bls381FqP"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-                         "h_query_launch": {"alg_bytes": (m - 1) * (32 + g1), "avg_ms": h_ms,
-                                            "achieved": (m - 1) * (32 + g1) / (h_ms * 1e-3) / 1e9},
-                         # the bound that actually binds: integer multiply issue.  One mixed add = 10 Montgomery
-                         # products of 2*N^2 v_mad_u64_u32 each (N = 8 / 12 limbs); peak = the measured chip-wide
-                         # v_mad_u64_u32 rate (tools/ubench.hip: 24.7 Top/s) / mads per product
-                         "valu": {"unit": "G field mults/s",
-                                  "achieved": (m - 1) * nwin * 10 / (h_ms * 1e-3) / 1e9,
-                                  "peak": 24.7e3 / (2 * (fq_limbs ** 2)),
-                                  "frac": (m - 1) * nwin * 10 / (h_ms * 1e-3) / 1e9 / (24.7e3 / (2 * (fq_limbs ** 2))),
-                                  "note": "H-query launch: (m-1) scalars x %d signed 16-bit digits x 10 products per mixed add" % nwin}},
-            "phase_ms_per_proof": {k: v / nprov for k, v in phase.items() if k.endswith("_ms")},
+                       "subcircuits_per_step": job.n_total, "n_constraints": circ.n_c, "n_variables": circ.n_v,
+                       "domain": m, "host_threads_per_gpu": args.threads,
+                       "sharding": "contiguous, %d subcircuits per rank (node.rs:471-493)" % args.subcircuits,
+                       "pk_classes_rank0": {str(k): len(v["members"]) for k, v in job.classes.items()},
+                       "exchange": "2 all_gathers per step (104 B + 328 B records), %s" % (backend if world > 1 else "local")},
+            "roofline": roof,
+            "per_rank_proofs_per_s": per_rank, "gather_ms_per_step": gather_ms,
+            "timed_proofs_check": checks,
+            "phase_ms_per_proof": {k: v / nprov for k, v in job.phase.items() if k.endswith("_ms")},
         }
-        if keep_host:
+        if want_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, circ, pk_host, fc)
+                mc = job.classes[job.main_class]
+                out["cpu_baseline"] = cpu_baseline(args, mc["circ"], mc["host"], job.fc)
             except Exception as e:       # noqa: BLE001
                 log("cpu baseline failed:", e)
                 out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary and args.curve == "bn254":
+            # the curve BASELINE.json's north_star names, same workload, one proving-key class, shorter run
+            try:
+                job.close()
+                job = None
+                j2 = Job(args, "bls12_381", 0, 1, dev, backend, single_class=True, witnesses=2)
+                s2 = max(2, min(args.steps, 4))
+                dt2 = timed_run(j2, s2, 1, barrier)
+                chk2 = None if args.no_verify else j2.verify_last_step()
+                _m2, roof2 = roofline_of(j2, "bls12_381")
+                out["secondary"] = {"curve": "bls12_381", "value": args.subcircuits * s2 / dt2, "unit": "proofs/s",
+                                    "steps": s2, "warmup": 1, "ms_per_step": dt2 / s2 * 1e3,
+                                    "pk_classes": 1, "timed_proofs_check": chk2,
+                                    "roofline": {k: roof2[k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms", "valu")}}
+                j2.close()
+            except Exception as e:       # noqa: BLE001
+                log("secondary (BLS12-381) run failed:", repr(e))
+                out["secondary"] = None
         print(json.dumps(out), flush=True)
+    if job is not None:
+        job.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

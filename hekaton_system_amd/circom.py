@@ -155,6 +155,8 @@ class R1CSFile:
             cols, vals = [], []
             for r, con in enumerate(self.constraints):
                 for idx, coeff in con[k]:
+                    if idx >= self.header.n_wires:       # a wire the header does not declare: out-of-bounds column
+                        raise InvalidData("constraint %d references wire %d of %d" % (r, idx, self.header.n_wires))
                     cols.append(col(idx))
                     vals.append(coeff)
                 row_ptr[r + 1] = len(cols)

@@ -276,6 +276,8 @@ class Trapdoor:                # toxic waste kept by TEST setups only (lets test
     c: list
     zt: int
     m: int
+    stage_ranges: list = None          # witness range of every stage (variable_range_for_stage)
+    n_inst: int = 0
 
 
 # --------------------------------------------------------------------------------------- setup
@@ -392,7 +394,8 @@ def generate_parameters(circuit, curve, rng, ctx, keep_on_device=False):
     pk = ProvingKey(vk=vk, beta_g=beta_g, a_g=fb(1, a, g1s), b_g=fb(1, b, g1s), b_h=fb(2, b, g2s),
                     h_g=fb(1, hq, g1s), ck=ck, deltas_g=deltas_g,
                     matrices=matrices, n_inst=n_inst, n_constraints=n_c)
-    td = Trapdoor(alpha, beta, gamma, deltas, t, g1s, g2s, a, b, c, zt, m)
+    td = Trapdoor(alpha, beta, gamma, deltas, t, g1s, g2s, a, b, c, zt, m,
+                  stage_ranges=list(cs.variable_range_for_stage), n_inst=n_inst)
     return pk, td
 
 
@@ -459,3 +462,53 @@ class CommitmentBuilder:
             raise AssertionError("deltas_g.len() == comm_rands.len() + 1")      # committer.rs:112
         a, b, c = CPGroth16.prove_last_stage_with_zk(self.cs, self.circuit, self.pk, rng, comm_rands)
         return Proof(a=a, b=b, c=c, ds=list(comms))
+
+
+# --------------------------------------------------------------------------------------- trapdoor verifier
+def trapdoor_verify(ctx, curve, td, n_inst, stage_ranges, z, h, comms, kappas, r_, s_, proof):
+    """Pairing-free acceptance test for proofs made under a TEST setup whose toxic waste `td` is known: recomputes
+    log A, log B, log C and log D_i in Fr, rebuilds the four group elements with the GPU fixed-base path
+    (hk_fixed_base_g1/g2 - a different kernel family from the prover's bucket MSMs) and compares bytes; then checks
+    the verifier equation of cp-groth16/src/verifier.rs:23-43 in the exponent:
+        log A * log B = alpha*beta + ic*gamma + sum_i D_i*delta_i + log C * delta_last.
+    z: full assignment ints; h: quotient coefficients ints (m of them); stage_ranges: [(start, end)] witness ranges
+    of every stage (MultiStageConstraintSystem.variable_range_for_stage); comms/kappas: one per earlier stage.
+    Returns None, raises AssertionError naming the first mismatch."""
+    p = CURVE_PARAMS[curve]
+    mod = p["r"]
+    fc = FrCodec(curve)
+    inv = lambda x: pow(x, -1, mod)
+    dl = td.deltas[-1]
+    az = sum(x * y for x, y in zip(z, td.a)) % mod
+    bz = sum(x * y for x, y in zip(z, td.b)) % mod
+    abc = [(td.beta * a + td.alpha * b + c) % mod for a, b, c in zip(td.a, td.b, td.c)]
+    log_a = (r_ * dl + az + td.alpha) % mod
+    log_b = (s_ * dl + bz + td.beta) % mod
+    ls, le = stage_ranges[-1]
+    l_log = sum(z[i] * abc[i] for i in range(n_inst + ls, n_inst + le)) % mod * inv(dl) % mod
+    hsum, tp = 0, 1
+    for i in range(td.m - 1):
+        hsum += h[i] * tp
+        tp = tp * td.t % mod
+    h_log = hsum % mod * td.zt % mod * inv(dl) % mod
+    log_c = (s_ * log_a + r_ * log_b - r_ * s_ % mod * dl + l_log + h_log) % mod
+    d_logs = []
+    for k, kappa in enumerate(kappas):
+        s0, e0 = stage_ranges[k]
+        d = sum(z[i] * abc[i] for i in range(n_inst + s0, n_inst + e0)) % mod * inv(td.deltas[k]) % mod
+        d_logs.append((d + kappa * dl) % mod)
+        log_c = (log_c - kappa * td.deltas[k]) % mod
+    G1, G2 = fc.g1(p["g1"]), fc.g2(p["g2"])
+    g1b = ctx.g1_bytes
+    want1 = np.asarray(ctx.fixed_base(1, G1, fc.enc([x * td.g1_scalar % mod for x in [log_a, log_c] + d_logs])))
+    want2 = np.asarray(ctx.fixed_base(2, G2, fc.enc([log_b * td.g2_scalar % mod])))
+    a, b, c = proof
+    assert bytes(np.asarray(a, np.uint8)) == bytes(want1[:g1b]), "proof.a is not [log A] g"
+    assert bytes(np.asarray(b, np.uint8)) == bytes(want2), "proof.b is not [log B] h"
+    assert bytes(np.asarray(c, np.uint8)) == bytes(want1[g1b:2 * g1b]), "proof.c is not [log C] g"
+    for k, com in enumerate(comms):
+        assert bytes(np.asarray(com, np.uint8)) == bytes(want1[(2 + k) * g1b:(3 + k) * g1b]), "commitment %d" % k
+    ic = sum(z[i] * abc[i] for i in range(n_inst)) % mod * inv(td.gamma) % mod
+    lhs = log_a * log_b % mod
+    rhs = (td.alpha * td.beta + ic * td.gamma + sum(d * dk for d, dk in zip(d_logs, td.deltas)) + log_c * dl) % mod
+    assert lhs == rhs, "Groth16 verifier equation (verifier.rs:23-43) does not hold in the exponent"

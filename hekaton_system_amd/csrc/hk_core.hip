@@ -32,9 +32,19 @@ LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
         if (ctx->lanes.size() < ctx->max_lanes) {
             Lane* l = new Lane();
             (void)hipSetDevice(ctx->device);
-            if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) { delete l; break; }
-            for (auto& e : l->ev) (void)hipEventCreate(&e);
-            for (auto& a : l->aux) (void)hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+            for (auto& e : l->ev) e = nullptr;
+            bool ok = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) == hipSuccess;
+            for (auto& e : l->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+            for (auto& a : l->aux) ok = ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess;
+            if (!ok) {                       // a half-built lane would run on the legacy default stream / null events
+                (void)hipGetLastError();
+                fprintf(stderr, "[hekaton] could not create the streams / events of a lane\n");
+                for (auto& e : l->ev) if (e) (void)hipEventDestroy(e);
+                for (auto& a : l->aux) if (a) (void)hipStreamDestroy(a);
+                if (l->stream) (void)hipStreamDestroy(l->stream);
+                delete l;
+                break;
+            }
             memset(&l->timings, 0, sizeof(l->timings));
             ctx->lanes.push_back(l);
             lane = l;

@@ -224,6 +224,23 @@ __global__ void k_spmv(const u64* __restrict__ row_ptr, const u32* __restrict__ 
     fr_store(&out[row], acc);
 }
 
+// Structural validation of a CSR matrix before any kernel indexes with it: row_ptr non-decreasing and within nnz,
+// every column < n_cols.  *bad becomes non-zero on the first violation (grid-stride over rows and non-zeros).
+template <int UNUSED>
+__global__ void k_csr_check(const u64* __restrict__ row_ptr, const u32* __restrict__ col, u64 n_rows, u64 nnz,
+                            u32 n_cols, u32* __restrict__ bad) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x, stride = (u64)gridDim.x * blockDim.x;
+    u32 f = 0;
+    for (u64 i = t; i < n_rows; i += stride) {
+        u64 b = row_ptr[i], e = row_ptr[i + 1];
+        if (b > e || e > nnz) f = 1;
+    }
+    for (u64 k = t; k < nnz; k += stride)
+        if (col[k] >= n_cols) f = 2;
+    if (t == 0 && (row_ptr[0] != 0 || row_ptr[n_rows] != nnz)) f = 3;
+    if (f) atomicOr(bad, f);
+}
+
 // a[n_c + j] = z[j] for j < n_inst  (witness_map_from_matrices: "a[start..end] = full_assignment[..num_inputs]")
 template <class Fr>
 __global__ void k_copy_inputs(Fr* __restrict__ a, const Fr* __restrict__ z, u32 n_c, u32 n_inst) {

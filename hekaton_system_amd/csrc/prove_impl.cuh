@@ -250,6 +250,23 @@ hk_status Ops<C>::ntt(hk_ctx* ctx, void* data, unsigned log_m, int inverse, int 
 // ---- witness map on device buffers --------------------------------------------------------------------
 struct CsrDev { const u64* row_ptr; const u32* col; const void* val; size_t n_rows, nnz; };
 
+// HK_ERR_ARG unless the (device-resident) matrix is structurally sound for n_cols variables: a malformed matrix
+// must come back as an error (the reference returns an ark error), never as an out-of-bounds device read.
+// `flag`: one u32 of device scratch.  Synchronises `s`.
+static hk_status csr_validate(hipStream_t s, const CsrDev& M, size_t n_cols, u32* flag) {
+    if (n_cols >= ((size_t)1 << 32)) return HK_ERR_ARG;
+    HK_HIP(hipMemsetAsync(flag, 0, sizeof(u32), s));
+    size_t work = M.n_rows > M.nnz ? M.n_rows : M.nnz;
+    u32 blocks = (u32)std::min<size_t>((work + 255) / 256, 2048);
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL((k_csr_check<0>), dim3(blocks), dim3(256), 0, s, M.row_ptr, M.col, (u64)M.n_rows, (u64)M.nnz,
+                       (u32)n_cols, flag);
+    u32 h = 0;
+    HK_HIP(hipMemcpyAsync(&h, flag, sizeof(u32), hipMemcpyDeviceToHost, s));
+    HK_HIP(hipStreamSynchronize(s));
+    return h ? HK_ERR_ARG : HK_OK;
+}
+
 template <class C>
 struct QapHost {
     typedef typename C::Fr Fr;
@@ -308,7 +325,9 @@ hk_status Ops<C>::witness_map(hk_ctx* ctx, const hk_csr* A, const hk_csr* B, con
                               size_t n_c, const void* z, size_t n_v, void* h_out, size_t h_cap,
                               size_t* m_out) {
     typedef QapHost<C> Q;
-    if (A->n_rows != n_c || B->n_rows != n_c || Cm->n_rows != n_c || n_inst > n_v) return HK_ERR_ARG;
+    if (A->n_rows != n_c || B->n_rows != n_c || Cm->n_rows != n_c || n_inst > n_v || n_inst < 1) return HK_ERR_ARG;
+    for (auto M : {A, B, Cm})
+        if (!M->row_ptr || (M->nnz && (!M->col || !M->val_mont))) return HK_ERR_ARG;
     u32 log_m = Q::domain_log(n_c, n_inst);
     if (log_m > C::TWO_ADICITY) return HK_ERR_DOMAIN_TOO_LARGE;
     size_t m = (size_t)1 << log_m;
@@ -319,7 +338,7 @@ hk_status Ops<C>::witness_map(hk_ctx* ctx, const hk_csr* A, const hk_csr* B, con
     LaneGuard g(ctx);
     Lane* L = g.lane;
     if (!L) return HK_ERR_DEVICE;
-    size_t need = 3 * m * sizeof(Fr) + n_v * sizeof(Fr) + 8192;
+    size_t need = 3 * m * sizeof(Fr) + n_v * sizeof(Fr) + 8192 + 256;
     const hk_csr* Ms[3] = {A, B, Cm};
     for (auto M : Ms) need += al256(8 * (M->n_rows + 1)) + al256(4 * M->nnz) + al256(sizeof(Fr) * M->nnz);
     HK_TRY(L->reserve(need));
@@ -331,6 +350,9 @@ hk_status Ops<C>::witness_map(hk_ctx* ctx, const hk_csr* A, const hk_csr* B, con
         HK_TRY(to_device(L, Ms[k]->val_mont, sizeof(Fr) * Ms[k]->nnz, &vl));
         D[k] = {(const u64*)rp, (const u32*)cl, vl, Ms[k]->n_rows, Ms[k]->nnz};
     }
+    u32* flag = L->alloc_n<u32>(1);
+    if (!flag) return HK_ERR_NOMEM;
+    for (int k = 0; k < 3; k++) HK_TRY(csr_validate(L->stream, D[k], n_v, flag));
     const void* zd;
     HK_TRY(to_device(L, z, n_v * sizeof(Fr), &zd));
     Fr* abc = L->alloc_n<Fr>(3 * m);
@@ -422,6 +444,22 @@ __global__ void k_gather(T* __restrict__ dst, const T* __restrict__ src, const u
     if (i < n_src) st_vec(&dst[k], ld_vec(&src[i]));
 }
 
+// error exits of pk_upload: release everything allocated so far (fail()) and tell out-of-memory from other faults
+#define PK_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            (void)hipGetLastError();                                                          \
+            fprintf(stderr, "[hekaton] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e), __FILE__, __LINE__, #expr); \
+            return fail(_e == hipErrorOutOfMemory ? HK_ERR_NOMEM : HK_ERR_DEVICE);            \
+        }                                                                                     \
+    } while (0)
+#define PK_TRY(expr)                               \
+    do {                                           \
+        hk_status _s = (expr);                     \
+        if (_s != HK_OK) return fail(_s);          \
+    } while (0)
+
 template <class C>
 hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
     typedef PkImpl<C> PK;
@@ -438,7 +476,8 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
     HK_HIP(hipSetDevice(ctx->device));
     PK* pk = new PK();
     hk_pk* h = new hk_pk{ctx->ops, ctx, pk};
-    auto fail = [&](hk_status st) { Ops<C>::pk_free(h); return st; };
+    void* staging = nullptr;                          // transient device copy of h_g (freed on every exit)
+    auto fail = [&](hk_status st) { if (staging) (void)hipFree(staging); Ops<C>::pk_free(h); return st; };
     pk->n_v = (u32)n_v; pk->n_inst = (u32)d->n_inst; pk->n_c = (u32)d->n_constraints;
     pk->n_stages = (u32)d->n_stages;
     u32 k = pk->n_stages - 1;
@@ -464,10 +503,10 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
     const char* delta_last_g = deltas + g1 * k;
     u32 shift = pz.c * pz.WP;
     if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->n_ext, &pk->a_tab)) != HK_OK) return fail(st);
-    HK_HIP(hipMemset(pk->a_tab, 0, g1 * pk->n_ext));
-    if (nq) HK_HIP(hipMemcpy(pk->a_tab, a_g + g1, g1 * nq, h2d_kind(a_g)));
-    HK_HIP(hipMemcpy(pk->a_tab + nq + 0, delta_last_g, g1, h2d_kind(deltas)));          // r * delta_g
-    HK_TRY(MsmRun<Fq>::build_tables(s0, pk->a_tab, pk->n_ext, pz.F, shift));
+    PK_HIP(hipMemset(pk->a_tab, 0, g1 * pk->n_ext));
+    if (nq) PK_HIP(hipMemcpy(pk->a_tab, a_g + g1, g1 * nq, h2d_kind(a_g)));
+    PK_HIP(hipMemcpy(pk->a_tab + nq + 0, delta_last_g, g1, h2d_kind(deltas)));          // r * delta_g
+    PK_TRY(MsmRun<Fq>::build_tables(s0, pk->a_tab, pk->n_ext, pz.F, shift));
     {
         // B-query: full-size staging copies on the device, then either used as the tables' first group
         // or compacted to the non-infinity bases
@@ -523,34 +562,34 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
         if (hipDeviceSynchronize() != hipSuccess) return tfail(HK_ERR_DEVICE);
         cleanup();
         u32 shift_b = pb.c * pb.WP;
-        HK_TRY(MsmRun<Fq>::build_tables(s0, pk->b1_tab, pk->b_n, pb.F, shift_b));
-        HK_TRY(MsmRun<Fq2>::build_tables(s0, pk->b2_tab, pk->b_n, pb.F, shift_b));
+        PK_TRY(MsmRun<Fq>::build_tables(s0, pk->b1_tab, pk->b_n, pb.F, shift_b));
+        PK_TRY(MsmRun<Fq2>::build_tables(s0, pk->b2_tab, pk->b_n, pb.F, shift_b));
     }
     // --- L table: last-stage committer key, then the negated deltas that fold -rs*delta and -kappa_i*delta_i
     size_t n1 = d->ck_len[k];
     pk->l_n = (u32)n1 + pk->n_extra;
     pk->l_off = (u32)(n_v - 1 - n1);                    // ext index of the first last-stage witness
     if ((st = pk_alloc_table(pk->owned, pk->bytes, pz.F, pk->l_n, &pk->l_tab)) != HK_OK) return fail(st);
-    HK_HIP(hipMemset(pk->l_tab, 0, g1 * pk->l_n));
-    if (n1) HK_HIP(hipMemcpy(pk->l_tab, d->ck_stage[k], g1 * n1, h2d_kind(d->ck_stage[k])));
+    PK_HIP(hipMemset(pk->l_tab, 0, g1 * pk->l_n));
+    if (n1) PK_HIP(hipMemcpy(pk->l_tab, d->ck_stage[k], g1 * n1, h2d_kind(d->ck_stage[k])));
     {
         std::vector<Affine<Fq>> dh(k + 1);
-        HK_HIP(hipMemcpy(dh.data(), deltas, g1 * (k + 1), is_device_ptr(deltas) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        PK_HIP(hipMemcpy(dh.data(), deltas, g1 * (k + 1), is_device_ptr(deltas) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
         std::vector<Affine<Fq>> neg(1 + k);
         neg[0] = dh[k].is_inf() ? dh[k] : ec_neg(dh[k]);                       // -delta_g  (scalar r*s)
         for (u32 i = 0; i < k; i++) neg[1 + i] = dh[i].is_inf() ? dh[i] : ec_neg(dh[i]);   // -delta_i (kappa_i)
-        HK_HIP(hipMemcpy(pk->l_tab + n1 + 2, neg.data(), g1 * (1 + k), hipMemcpyHostToDevice));
+        PK_HIP(hipMemcpy(pk->l_tab + n1 + 2, neg.data(), g1 * (1 + k), hipMemcpyHostToDevice));
     }
-    HK_TRY(MsmRun<Fq>::build_tables(s0, pk->l_tab, pk->l_n, pz.F, shift));
+    PK_TRY(MsmRun<Fq>::build_tables(s0, pk->l_tab, pk->l_n, pz.F, shift));
     // --- per-stage commitment tables: ck[stage] | last_delta_g (scalar kappa)
     for (u32 sidx = 0; sidx < pk->n_stages; sidx++) {
         size_t n = d->ck_len[sidx] + 1;
         MsmPlan p = make_plan(n);
         Affine<Fq>* tab;
         if ((st = pk_alloc_table(pk->owned, pk->bytes, p.F, n, &tab)) != HK_OK) return fail(st);
-        if (n > 1) HK_HIP(hipMemcpy(tab, d->ck_stage[sidx], g1 * (n - 1), h2d_kind(d->ck_stage[sidx])));
-        HK_HIP(hipMemcpy(tab + n - 1, delta_last_g, g1, h2d_kind(deltas)));
-        HK_TRY(MsmRun<Fq>::build_tables(s0, tab, (u32)n, p.F, p.c * p.WP));
+        if (n > 1) PK_HIP(hipMemcpy(tab, d->ck_stage[sidx], g1 * (n - 1), h2d_kind(d->ck_stage[sidx])));
+        PK_HIP(hipMemcpy(tab + n - 1, delta_last_g, g1, h2d_kind(deltas)));
+        PK_TRY(MsmRun<Fq>::build_tables(s0, tab, (u32)n, p.F, p.c * p.WP));
         pk->plan_ck.push_back(p);
         pk->ck_tab.push_back(tab);
         pk->ck_n.push_back((u32)n);
@@ -558,15 +597,15 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
     // --- constants for the finish kernel
     {
         void* p1; void* p2;
-        HK_HIP(hipMalloc(&p1, g1 * 4)); pk->owned.push_back(p1);
-        HK_HIP(hipMalloc(&p2, g2 * 2)); pk->owned.push_back(p2);
+        PK_HIP(hipMalloc(&p1, g1 * 4)); pk->owned.push_back(p1);
+        PK_HIP(hipMalloc(&p2, g2 * 2)); pk->owned.push_back(p2);
         pk->consts_g1 = (Affine<Fq>*)p1; pk->consts_g2 = (Affine<Fq2>*)p2;
-        HK_HIP(hipMemcpy(pk->consts_g1 + 0, a_g, g1, h2d_kind(a_g)));
-        HK_HIP(hipMemcpy(pk->consts_g1 + 1, d->alpha_g, g1, h2d_kind(d->alpha_g)));
-        HK_HIP(hipMemcpy(pk->consts_g1 + 2, b_g, g1, h2d_kind(b_g)));
-        HK_HIP(hipMemcpy(pk->consts_g1 + 3, d->beta_g, g1, h2d_kind(d->beta_g)));
-        HK_HIP(hipMemcpy(pk->consts_g2 + 0, b_h, g2, h2d_kind(b_h)));
-        HK_HIP(hipMemcpy(pk->consts_g2 + 1, d->beta_h, g2, h2d_kind(d->beta_h)));
+        PK_HIP(hipMemcpy(pk->consts_g1 + 0, a_g, g1, h2d_kind(a_g)));
+        PK_HIP(hipMemcpy(pk->consts_g1 + 1, d->alpha_g, g1, h2d_kind(d->alpha_g)));
+        PK_HIP(hipMemcpy(pk->consts_g1 + 2, b_g, g1, h2d_kind(b_g)));
+        PK_HIP(hipMemcpy(pk->consts_g1 + 3, d->beta_g, g1, h2d_kind(d->beta_g)));
+        PK_HIP(hipMemcpy(pk->consts_g2 + 0, b_h, g2, h2d_kind(b_h)));
+        PK_HIP(hipMemcpy(pk->consts_g2 + 1, d->beta_h, g2, h2d_kind(d->beta_h)));
     }
     // --- QAP: matrices + H-query in bit-reversed order
     if (d->A && d->B && d->C) {
@@ -580,39 +619,49 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
         const hk_csr* Ms[3] = {d->A, d->B, d->C};
         for (int i = 0; i < 3; i++) {
             void *rp, *cl, *vl;
-            HK_HIP(hipMalloc(&rp, 8 * (Ms[i]->n_rows + 1))); pk->owned.push_back(rp);
-            HK_HIP(hipMalloc(&cl, 4 * Ms[i]->nnz + 16)); pk->owned.push_back(cl);
-            HK_HIP(hipMalloc(&vl, sizeof(Fr) * Ms[i]->nnz + 16)); pk->owned.push_back(vl);
-            HK_HIP(hipMemcpy(rp, Ms[i]->row_ptr, 8 * (Ms[i]->n_rows + 1), h2d_kind(Ms[i]->row_ptr)));
+            PK_HIP(hipMalloc(&rp, 8 * (Ms[i]->n_rows + 1))); pk->owned.push_back(rp);
+            PK_HIP(hipMalloc(&cl, 4 * Ms[i]->nnz + 16)); pk->owned.push_back(cl);
+            PK_HIP(hipMalloc(&vl, sizeof(Fr) * Ms[i]->nnz + 16)); pk->owned.push_back(vl);
+            PK_HIP(hipMemcpy(rp, Ms[i]->row_ptr, 8 * (Ms[i]->n_rows + 1), h2d_kind(Ms[i]->row_ptr)));
+            if (!Ms[i]->row_ptr || (Ms[i]->nnz && (!Ms[i]->col || !Ms[i]->val_mont))) return fail(HK_ERR_ARG);
             if (Ms[i]->nnz) {
-                HK_HIP(hipMemcpy(cl, Ms[i]->col, 4 * Ms[i]->nnz, h2d_kind(Ms[i]->col)));
-                HK_HIP(hipMemcpy(vl, Ms[i]->val_mont, sizeof(Fr) * Ms[i]->nnz, h2d_kind(Ms[i]->val_mont)));
+                PK_HIP(hipMemcpy(cl, Ms[i]->col, 4 * Ms[i]->nnz, h2d_kind(Ms[i]->col)));
+                PK_HIP(hipMemcpy(vl, Ms[i]->val_mont, sizeof(Fr) * Ms[i]->nnz, h2d_kind(Ms[i]->val_mont)));
             }
             pk->csr[i] = {(const u64*)rp, (const u32*)cl, vl, Ms[i]->n_rows, Ms[i]->nnz};
             pk->bytes += 8 * (Ms[i]->n_rows + 1) + (4 + sizeof(Fr)) * Ms[i]->nnz;
         }
+        {
+            // a malformed matrix (column >= n_v, row_ptr not monotone / not ending at nnz) is HK_ERR_ARG here,
+            // not an out-of-bounds read in every later hk_prove
+            void* flag = nullptr;
+            PK_HIP(hipMalloc(&flag, 256)); pk->owned.push_back(flag);
+            for (int i = 0; i < 3; i++) PK_TRY(csr_validate(s0, pk->csr[i], n_v, (u32*)flag));
+        }
         pk->plan_h = make_plan(m);
         if ((st = pk_alloc_table(pk->owned, pk->bytes, pk->plan_h.F, m, &pk->h_tab)) != HK_OK) return fail(st);
         const Affine<Fq>* src = (const Affine<Fq>*)d->h_g;
-        void* tmp = nullptr;
         if (!is_device_ptr(d->h_g)) {
-            HK_HIP(hipMalloc(&tmp, g1 * (d->h_len ? d->h_len : 1)));
-            HK_HIP(hipMemcpy(tmp, d->h_g, g1 * d->h_len, hipMemcpyHostToDevice));
-            src = (const Affine<Fq>*)tmp;
+            PK_HIP(hipMalloc(&staging, g1 * (d->h_len ? d->h_len : 1)));
+            PK_HIP(hipMemcpy(staging, d->h_g, g1 * d->h_len, hipMemcpyHostToDevice));
+            src = (const Affine<Fq>*)staging;
         }
         hipLaunchKernelGGL((k_pk_bitrev_copy<Fq>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s0, pk->h_tab,
                            src, (u32)d->h_len, pk->log_m);
-        HK_HIP(hipDeviceSynchronize());
-        if (tmp) HK_HIP(hipFree(tmp));
-        HK_TRY(MsmRun<Fq>::build_tables(s0, pk->h_tab, (u32)m, pk->plan_h.F, pk->plan_h.c * pk->plan_h.WP));
+        PK_HIP(hipDeviceSynchronize());
+        if (staging) { (void)hipFree(staging); staging = nullptr; }
+        PK_TRY(MsmRun<Fq>::build_tables(s0, pk->h_tab, (u32)m, pk->plan_h.F, pk->plan_h.c * pk->plan_h.WP));
         NttTables* T;
-        HK_TRY(NttHost<C>::ensure(ctx, pk->log_m, &T));
+        PK_TRY(NttHost<C>::ensure(ctx, pk->log_m, &T));
         pk->has_qap = true;
     }
-    HK_HIP(hipDeviceSynchronize());
+    PK_HIP(hipDeviceSynchronize());
     *out = h;
     return HK_OK;
 }
+
+#undef PK_HIP
+#undef PK_TRY
 
 template <class C>
 void Ops<C>::pk_free(hk_pk* h) {
@@ -873,6 +922,7 @@ static inline float ev_ms(hipEvent_t a, hipEvent_t b) {
 template <class C>
 hk_status Ops<C>::commit(hk_ctx* ctx, const hk_pk* h, size_t stage, const void* w, size_t n,
                          const void* kappa, void* out) {
+    if (h->ctx != ctx) return HK_ERR_ARG;                  // a key lives on the context (device) that uploaded it
     PkImpl<C>* pk = (PkImpl<C>*)h->impl;
     if (stage >= pk->n_stages) return HK_ERR_ARG;          // "no more values left in committing key"
     if (n + 1 != pk->ck_n[stage]) return HK_ERR_LEN;       // committer.rs:83
@@ -918,6 +968,7 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
                         const void* s_m, const void* kappas, size_t n_kappas, void* out_a, void* out_b,
                         void* out_c) {
     typedef QapHost<C> Q;
+    if (h->ctx != ctx) return HK_ERR_ARG;
     PkImpl<C>* pk = (PkImpl<C>*)h->impl;
     if (!pk->has_qap) return HK_ERR_ARG;
     if (n_v != pk->n_v) return HK_ERR_LEN;
@@ -991,6 +1042,16 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     static const bool serial = getenv("HK_SERIAL_STREAMS") != nullptr;   // profiling aid: clean per-kernel times
     if (serial) for (auto& a : axs) a = s;
     hipStream_t* ax = axs;
+    // Every exit between the fork and the join - an HK_TRY / HK_HIP return included - must leave no side stream
+    // running on this lane's arena: the next call on the lane resets the arena and would reuse live memory.
+    struct JoinGuard {
+        hipStream_t main; hipStream_t* aux; bool joined = false;
+        ~JoinGuard() {
+            if (joined) return;
+            for (int i = 0; i < 4; i++) (void)hipStreamSynchronize(aux[i]);
+            (void)hipStreamSynchronize(main);
+        }
+    } join_guard{s, axs};
     hipEvent_t ev_z = ev[16], ev_sorted = ev[17];
     HK_HIP(hipEventRecord(ev_z, s));                                           // z (and ext scalars) on device
     HK_HIP(hipStreamWaitEvent(ax[3], ev_z, 0));
@@ -1035,6 +1096,7 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     HK_HIP(hipStreamWaitEvent(s, ev[4], 0));
     HK_HIP(hipStreamWaitEvent(s, ev[18], 0));
     HK_HIP(hipStreamWaitEvent(s, ev[7], 0));
+    join_guard.joined = true;                                                  // main now depends on every side stream
     if (prof) HK_HIP(hipEventRecord(ev[19], s));                               // all queries done
     hipLaunchKernelGGL((k_finish<Fr, Fq, Fq2>), dim3(3), dim3(64), 0, s, res1, res2, pk->consts_g1,
                        pk->consts_g2, small, oa, ob, oa + 1);

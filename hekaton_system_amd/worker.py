@@ -10,7 +10,9 @@
 The reference scatters requests and gathers responses with MPI (rank 0 = coordinator).  Here every
 rank is a worker on its own GPU; subcircuits are sharded contiguously and the fixed-size response
 records are all-gathered with torch.distributed (RCCL on GPUs, gloo in the CPU tests).  There is no
-collective on the data path: a response is 104 B (stage 0) / 264 B (stage 1) for BN254.
+collective on the data path: a response record is 104 B (stage 0) / 328 B (stage 1: idx + A + B + C + one
+stage-0 commitment) for BN254; the ark-serialize framings of the same responses are 104 B / 336 B
+(ark_serialize.py: the `Vec` of commitments carries an 8-byte length).
 """
 from dataclasses import dataclass, field
 

@@ -74,3 +74,13 @@ def test_to_csr_column_mapping():
     assert list(A[1][:2]) == [5 + 1, 6 + 1]
     fc = FrCodec("bn254")
     assert fc.dec(A[2][:64]) == [3, 8]
+
+
+def test_wire_index_beyond_header_is_invalid_data():
+    """A constraint that names a wire >= n_wires (truncated / malformed file) must be InvalidData at to_csr time, not
+    an out-of-bounds column handed to the GPU (hk_pk_upload would answer HK_ERR_ARG; the parser says it first)."""
+    file = circom.R1CSFile.new(_data("circom_sample.r1cs"))
+    a, b, c = file.constraints[0]
+    file.constraints[0] = ([(file.header.n_wires, 1)] + list(a[1:]), b, c)
+    with pytest.raises(circom.InvalidData):
+        file.to_csr(FrCodec("bn254"))

@@ -159,3 +159,67 @@ def test_resident_bases_msm_matches_plain_msm_and_oracle(group, ctx_bn254):
     empty = ctx_bn254.bases_upload(group, np.zeros(0, np.uint8), n=0)
     assert not empty.msm(np.zeros(0, np.uint8)).any()
     empty.free()
+
+
+def _tiny_key(ctx, seed=5):
+    cp = BN254
+    cd = Codec(cp)
+    rnd = random.Random(seed)
+    cs = synthetic_r1cs(cp, rnd, n_inst=2, n_free=6, n_c=12, two_stage_split=2)
+    pk, td = groth16.generate_parameters(cp, cs, 3, 5, 7, [11, 13], 17, 2, 3)
+    return cp, cd, cs, pk
+
+
+def test_malformed_csr_is_an_argument_error_not_a_device_fault(ctx_bn254):
+    """hk_witness_map / hk_pk_upload validate the matrices they are about to index with: a column
+    >= n_v, a non-monotone row_ptr, a row_ptr that does not end at nnz, n_inst = 0 -> HK_ERR_ARG."""
+    cp, cd, cs, pk = _tiny_key(ctx_bn254)
+    A, B, C = (csr_from_rows(cd, M) for M in cs.matrices())
+    z = cd.fr_vec_mont(cs.full_assignment())
+    n_v = len(cs.full_assignment())
+    ok, _m = ctx_bn254.witness_map(A, B, C, cs.num_instance, cs.num_constraints, z)
+    assert len(ok)
+
+    def expect_arg(A_, B_, C_, n_inst=cs.num_instance):
+        with pytest.raises(capi.HekatonError) as e:
+            ctx_bn254.witness_map(A_, B_, C_, n_inst, cs.num_constraints, z)
+        assert e.value.status == capi.HK_ERR_ARG
+
+    bad_col = (A[0], A[1].copy(), A[2]); bad_col[1][0] = n_v            # column index one past the assignment
+    expect_arg(bad_col, B, C)
+    bad_rp = (B[0].copy(), B[1], B[2]); bad_rp[0][1], bad_rp[0][2] = bad_rp[0][2] + 1, bad_rp[0][1]   # not monotone
+    expect_arg(A, bad_rp, C)
+    bad_end = (C[0].copy(), C[1], C[2]); bad_end[0][-1] += 1                                          # != nnz
+    expect_arg(A, B, bad_end)
+    expect_arg(A, B, C, n_inst=0)
+    # the same matrices refused at key upload
+    with pytest.raises(capi.HekatonError) as e:
+        ctx_bn254.pk_upload(
+            a_g=cd.g1_vec(pk.a_g), b_g=cd.g1_vec(pk.b_g), b_h=cd.g2_vec(pk.b_h), h_g=cd.g1_vec(pk.h_g),
+            ck_stages=[cd.g1_vec(v) for v in pk.ck.deltas_abc_g], deltas_g=cd.g1_vec(pk.deltas_g),
+            last_delta_h=cd.g2_vec([pk.last_delta_h()]), alpha_g=cd.g1_vec([pk.vk.alpha_g]),
+            beta_g=cd.g1_vec([pk.beta_g]), beta_h=cd.g2_vec([pk.vk.beta_h]), matrices=(bad_col, B, C),
+            n_inst=cs.num_instance, n_constraints=cs.num_constraints)
+    assert e.value.status == capi.HK_ERR_ARG
+    # and the context still works afterwards
+    again, _ = ctx_bn254.witness_map(A, B, C, cs.num_instance, cs.num_constraints, z)
+    assert np.array_equal(ok, again)
+
+
+def test_key_of_another_context_is_refused(ctx_bn254):
+    """hk_commit / hk_prove check pk->ctx == ctx, as hk_msm_bases does."""
+    cp, cd, cs, pk = _tiny_key(ctx_bn254, seed=6)
+    dpk = pk_upload_from_oracle(ctx_bn254, cd, pk, cs)
+    other = capi.Context("bn254", 0)
+    try:
+        stolen = capi.DevicePk(other, dpk.handle)
+        w0 = cd.fr_vec_mont(cs.stage_witness(0))
+        with pytest.raises(capi.HekatonError) as e:
+            stolen.commit(0, w0, cd.fr_vec_mont([3]))
+        assert e.value.status == capi.HK_ERR_ARG
+        with pytest.raises(capi.HekatonError) as e:
+            stolen.prove(cd.fr_vec_mont(cs.full_assignment()), cd.fr_vec_mont([1]), cd.fr_vec_mont([2]), cd.fr_vec_mont([3]))
+        assert e.value.status == capi.HK_ERR_ARG
+    finally:
+        other.close()
+        dpk.free()
