@@ -141,7 +141,7 @@ def cpu_baseline(args, circ, pk_host, fc):
     one(0)
     lat = time.time() - t0
     # bounded sample: enough rounds of `conc` concurrent proofs for ~15-25 s of wall clock
-    rounds = max(1, min(3, int(20.0 / max(lat, 1e-3))))
+    rounds = 1 if conc >= 4 else max(1, min(3, int(20.0 / max(lat, 1e-3))))
     n = conc * rounds
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=conc) as pool:
@@ -154,43 +154,66 @@ def cpu_baseline(args, circ, pk_host, fc):
 
 
 # ------------------------------------------------------------------------------------------- one measured job
+def plan_classes(args, rank, world, single_class):
+    """Which subcircuit indices this rank proves, the proving-key class of each, and the host-side setup jobs."""
+    from hekaton_system_amd.workload import config_classes, representative_subcircuit
+    from hekaton_system_amd.worker import shard_range
+    family, _n_default, _reps = config_classes(args.config)
+    n_total = args.subcircuits * world
+    shard = list(shard_range(n_total, world, rank))
+    if single_class:
+        class_of = {i: 1 for i in shard}
+    else:
+        class_of = {i: representative_subcircuit(family, n_total, i) for i in shard}
+    return n_total, shard, class_of
+
+
+def prepare_job_host(args, curve, rank, world, single_class=False, witnesses=None):
+    """Host half of a Job (no device, no HIP): per proving-key class of the rank's shard, the trusted setup's scalar
+    work and the assignments, in parallel worker processes.  Called BEFORE anything initialises the GPU."""
+    from hekaton_system_amd.workload import prepare_classes_host
+    n_total, shard, class_of = plan_classes(args, rank, world, single_class)
+    need = sorted(set(class_of.values()))
+    nw = witnesses or args.witnesses
+    jobs = []
+    for rep in need:
+        members = [i for i in shard if class_of[i] == rep]
+        k = min(nw, len(members))
+        seed = hashlib.sha256(b"HEKATON1 class %d" % rep).digest()
+        jobs.append((curve, args.config, rep, seed, [1000 * rep + j + 1 for j in range(k)]))
+    t0 = time.time()
+    out = {rep: (hs, assigns) for rep, hs, assigns in prepare_classes_host(jobs)}
+    log("rank %d: %s host setup of %d proving-key class(es) %s in %.1f s" % (rank, curve, len(need), need, time.time() - t0))
+    return dict(n_total=n_total, shard=shard, class_of=class_of, classes=out, curve=curve)
+
+
 class Job:
     """Keys, assignments and the step function of one (curve, config) on one rank."""
 
-    def __init__(self, args, curve, rank, world, dev, backend, single_class=False, keep_host=False,
-                 witnesses=None):
+    def __init__(self, args, prepared, rank, world, dev, backend, keep_host=False):
         from hekaton_system_amd import capi
-        from hekaton_system_amd.cp_groth16 import FrCodec, SeededRng, generate_parameters
-        from hekaton_system_amd.workload import config_classes, make_config, representative_subcircuit
-        from hekaton_system_amd.worker import shard_range
+        from hekaton_system_amd.cp_groth16 import FrCodec, setup_device
+        from hekaton_system_amd.workload import make_config
+        curve = prepared["curve"]
         self.args, self.curve, self.rank, self.world, self.backend = args, curve, rank, world, backend
         self.capi = capi
         self.ctx = capi.Context(curve, dev)
         self.fc = FrCodec(curve)
-        family, _n_default, _reps = config_classes(args.config)
-        self.family = family
-        S = args.subcircuits
-        self.n_total = S * world
-        self.shard = list(shard_range(self.n_total, world, rank))
-        if single_class:
-            self.class_of = {i: 1 for i in self.shard}
-        else:
-            self.class_of = {i: representative_subcircuit(family, self.n_total, i) for i in self.shard}
-        need = sorted(set(self.class_of.values()))
+        self.n_total, self.shard, self.class_of = prepared["n_total"], prepared["shard"], prepared["class_of"]
+        need = sorted(prepared["classes"])
         count = {rep: sum(1 for i in self.shard if self.class_of[i] == rep) for rep in need}
         self.main_class = max(need, key=lambda rep: (count[rep], -rep))      # the shard's most common class
         keep_host_class = self.main_class if keep_host else None
-        nw = witnesses or args.witnesses
         self.classes = {}
         t0 = time.time()
         for rep in need:
+            hs, assigns = prepared["classes"][rep]
             circ = make_config(curve, args.config, rep)
-            seed = hashlib.sha256(b"HEKATON1 class %d" % rep).digest()
-            keep_host = keep_host_class is not None and rep == keep_host_class
-            pk, td = generate_parameters(circ, curve, SeededRng(seed), self.ctx, keep_on_device=not keep_host)
+            keep = keep_host_class is not None and rep == keep_host_class
+            pk, td = setup_device(hs, self.ctx, keep_on_device=not keep)
             dpk = pk.upload(self.ctx)
             host = None
-            if keep_host:
+            if keep:
                 host = {"points": dict(a_g=pk.a_g, b_g=pk.b_g, b_h=pk.b_h, h_g=pk.h_g, ck_stages=pk.ck.deltas_abc_g,
                                        deltas_g=pk.deltas_g, last_delta_h=pk.vk.last_delta_h, alpha_g=pk.vk.alpha_g,
                                        beta_g=pk.beta_g, beta_h=pk.vk.beta_h),
@@ -200,19 +223,16 @@ class Job:
                     if isinstance(b, capi.DeviceBuffer):
                         b.free()
             members = [i for i in self.shard if self.class_of[i] == rep]
-            k = min(nw, len(members))
             zs, w0s, seeds = [], [], []
-            for j in range(k):
-                ws = 1000 * rep + j + 1
-                circ.set_witness_seed(ws)
-                zb, wb = circ.full_assignment_bytes(), circ.stage0_witness_bytes()
+            for ws, zb, wb in assigns:
                 zs.append(zb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, zb))
                 w0s.append(wb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, wb))
                 seeds.append(ws)
             self.classes[rep] = dict(circ=circ, pk=pk, td=td, dpk=dpk, host=host, zs=zs, w0s=w0s, seeds=seeds,
                                      members=members, matrices=pk.matrices)
             log("rank %d: %s class %d (%d subcircuits of this shard): key + %d assignments resident, %.1f s" % (
-                rank, curve, rep, len(members), k, time.time() - t0))
+                rank, curve, rep, len(members), len(zs), time.time() - t0))
+        prepared["classes"] = None                   # the host copies are no longer needed
         self.circ = self.classes[self.main_class]["circ"]
         # which assignment a subcircuit uses: its position within its class, cycled
         self.assign_of = {}
@@ -402,8 +422,18 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or run without a launcher and let "
                  "bench.py start the ranks itself)" % (args.gpus, world))
+    # stdout carries exactly one line (rank 0's JSON): everything libraries print there (gloo's "[Gloo] Rank 0 is
+    # connected ..." chatter, RCCL banners) is sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("HK_BENCH_ECHO_RANK"):
         log("rank %d of %d starting (pid %d)" % (rank, world, os.getpid()))
+    # host half of every job first: spawned worker processes, before this process touches HIP
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    want_secondary = rank == 0 and world == 1 and not args.no_secondary and args.curve == "bn254"
+    prep = prepare_job_host(args, args.curve, rank, world, single_class=args.single_class)
+    prep2 = prepare_job_host(args, "bls12_381", 0, 1, single_class=True, witnesses=2) if want_secondary else None
     from hekaton_system_amd import capi          # noqa: F401  first: exports GPU_MAX_HW_QUEUES before HIP initialises
     import torch
     import torch.distributed as dist
@@ -425,8 +455,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    job = Job(args, args.curve, rank, world, dev, backend, single_class=args.single_class, keep_host=want_cpu)
+    job = Job(args, prep, rank, world, dev, backend, keep_host=want_cpu)
     circ = job.circ
     dt_local = timed_run(job, args.steps, args.warmup, barrier)
     dt = dt_local
@@ -478,12 +507,12 @@ def main():
             except Exception as e:       # noqa: BLE001
                 log("cpu baseline failed:", e)
                 out["cpu_baseline"] = None
-        if world == 1 and not args.no_secondary and args.curve == "bn254":
+        if want_secondary:
             # the curve BASELINE.json's north_star names, same workload, one proving-key class, shorter run
             try:
                 job.close()
                 job = None
-                j2 = Job(args, "bls12_381", 0, 1, dev, backend, single_class=True, witnesses=2)
+                j2 = Job(args, prep2, 0, 1, dev, backend)
                 s2 = max(2, min(args.steps, 4))
                 dt2 = timed_run(j2, s2, 1, barrier)
                 chk2 = None if args.no_verify else j2.verify_last_step()
@@ -496,7 +525,7 @@ def main():
             except Exception as e:       # noqa: BLE001
                 log("secondary (BLS12-381) run failed:", repr(e))
                 out["secondary"] = None
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if job is not None:
         job.close()
     if world > 1:

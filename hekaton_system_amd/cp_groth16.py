@@ -328,10 +328,29 @@ def qap_instance_map_with_evaluation(curve, A, B, C, n_inst, n_wit, n_c, t):
     return a, b, c, zt, m
 
 
-def generate_parameters(circuit, curve, rng, ctx, keep_on_device=False):
-    """generator.rs:18-238.  Synthesises every stage in setup mode, evaluates the QAP at a random
-    point on the host, then runs the fixed-base MSMs on the GPU (hk_fixed_base_g1/g2).
-    Returns (ProvingKey, Trapdoor)."""
+@dataclass
+class HostSetup:
+    """Everything `generate_parameters` computes in the scalar field on the host (generator.rs:28-117,182), ready for
+    the fixed-base MSMs: canonical little-endian scalar arrays, the class's CSR matrices and the toxic waste.  Pure
+    Python / numpy - no device - so several classes can be prepared in parallel worker processes (bench.py)."""
+    curve: str
+    sc_small1: np.ndarray          # [alpha, beta] + deltas + gamma_abc, times the G1 generator scalar (Montgomery)
+    sc_small2: np.ndarray          # [beta, gamma] + deltas, times the G2 generator scalar (Montgomery)
+    sc_ck: list                    # per stage: deltas_abc * g1s (Montgomery)
+    sc_a_g1: np.ndarray            # canonical
+    sc_b_g1: np.ndarray
+    sc_b_g2: np.ndarray
+    sc_h_g1: np.ndarray
+    matrices: tuple
+    n_inst: int
+    n_constraints: int
+    n_stages: int
+    td: Trapdoor
+
+
+def setup_host(circuit, curve, rng):
+    """Host half of generator.rs:18-238: synthesise every stage in setup mode, draw the toxic waste, evaluate the QAP
+    at t, and lay out every scalar the fixed-base MSMs need."""
     p = CURVE_PARAMS[curve]
     r = p["r"]
     fc = FrCodec(curve)
@@ -365,22 +384,37 @@ def generate_parameters(circuit, curve, rng, ctx, keep_on_device=False):
     for i in range(m - 1):
         hq[i] = cur
         cur = cur * t % r
-    # group generators g = g1s * G, h = g2s * H; every key element is (scalar * g1s) * G etc.
+    td = Trapdoor(alpha, beta, gamma, deltas, t, g1s, g2s, a, b, c, zt, m,
+                  stage_ranges=list(cs.variable_range_for_stage), n_inst=n_inst)
+    canon = lambda xs, mult: fc.enc_canon([x * mult % r for x in xs])
+    return HostSetup(
+        curve=curve,
+        sc_small1=fc.enc([x * g1s % r for x in [alpha, beta] + deltas + gamma_abc]),
+        sc_small2=fc.enc([x * g2s % r for x in [beta, gamma] + deltas]),
+        sc_ck=[fc.enc([x * g1s % r for x in v]) for v in deltas_abc],
+        sc_a_g1=canon(a, g1s), sc_b_g1=canon(b, g1s), sc_b_g2=canon(b, g2s), sc_h_g1=canon(hq, g1s),
+        matrices=matrices, n_inst=n_inst, n_constraints=n_c, n_stages=len(deltas), td=td)
+
+
+def setup_device(hs, ctx, keep_on_device=False):
+    """Device half of generator.rs:126-224: the fixed-base MSMs (hk_fixed_base_g1/g2) over a HostSetup.
+    Every key element is (scalar * generator scalar) * G.  Returns (ProvingKey, Trapdoor)."""
+    p = CURVE_PARAMS[hs.curve]
+    fc = FrCodec(hs.curve)
     G1, G2 = fc.g1(p["g1"]), fc.g2(p["g2"])
 
-    def fb(group, scalars, mult):
-        enc = fc.enc_canon([s * mult % r for s in scalars])
+    def fb(group, enc):
+        n = len(enc) // fc.nb
         if keep_on_device:
-            n = len(scalars)
             out = capi.DeviceBuffer(ctx, n * (ctx.g1_bytes if group == 1 else ctx.g2_bytes))
             ctx.fixed_base(group, G1 if group == 1 else G2, enc, n=n, montgomery=False, out=out)
             return out
         return ctx.fixed_base(group, G1 if group == 1 else G2, enc, montgomery=False)
 
-    small1 = ctx.fixed_base(1, G1, fc.enc([x * g1s % r for x in [alpha, beta] + deltas + gamma_abc]))
-    small2 = ctx.fixed_base(2, G2, fc.enc([x * g2s % r for x in [beta, gamma] + deltas]))
+    small1 = ctx.fixed_base(1, G1, hs.sc_small1)
+    small2 = ctx.fixed_base(2, G2, hs.sc_small2)
     g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
-    k = len(deltas)
+    k = hs.n_stages
     alpha_g, beta_g = small1[:g1b], small1[g1b:2 * g1b]
     deltas_g = small1[2 * g1b:(2 + k) * g1b]
     gamma_abc_g = small1[(2 + k) * g1b:]
@@ -389,14 +423,19 @@ def generate_parameters(circuit, curve, rng, ctx, keep_on_device=False):
     vk = VerifyingKey(alpha_g=alpha_g, beta_h=beta_h, gamma_h=gamma_h, last_delta_h=deltas_h[-g2b:],
                       gamma_abc_g=gamma_abc_g, deltas_h=deltas_h)
     ck = CommitterKey(last_delta_g=deltas_g[-g1b:],
-                      deltas_abc_g=[np.asarray(ctx.fixed_base(1, G1, fc.enc([s * g1s % r for s in v])))
-                                    if len(v) else np.zeros(0, np.uint8) for v in deltas_abc])
-    pk = ProvingKey(vk=vk, beta_g=beta_g, a_g=fb(1, a, g1s), b_g=fb(1, b, g1s), b_h=fb(2, b, g2s),
-                    h_g=fb(1, hq, g1s), ck=ck, deltas_g=deltas_g,
-                    matrices=matrices, n_inst=n_inst, n_constraints=n_c)
-    td = Trapdoor(alpha, beta, gamma, deltas, t, g1s, g2s, a, b, c, zt, m,
-                  stage_ranges=list(cs.variable_range_for_stage), n_inst=n_inst)
-    return pk, td
+                      deltas_abc_g=[np.asarray(ctx.fixed_base(1, G1, v)) if len(v) else np.zeros(0, np.uint8)
+                                    for v in hs.sc_ck])
+    pk = ProvingKey(vk=vk, beta_g=beta_g, a_g=fb(1, hs.sc_a_g1), b_g=fb(1, hs.sc_b_g1), b_h=fb(2, hs.sc_b_g2),
+                    h_g=fb(1, hs.sc_h_g1), ck=ck, deltas_g=deltas_g,
+                    matrices=hs.matrices, n_inst=hs.n_inst, n_constraints=hs.n_constraints)
+    return pk, hs.td
+
+
+def generate_parameters(circuit, curve, rng, ctx, keep_on_device=False):
+    """generator.rs:18-238.  Synthesises every stage in setup mode, evaluates the QAP at a random
+    point on the host (setup_host), then runs the fixed-base MSMs on the GPU (setup_device).
+    Returns (ProvingKey, Trapdoor)."""
+    return setup_device(setup_host(circuit, curve, rng), ctx, keep_on_device)
 
 
 # --------------------------------------------------------------------------------------- prover

@@ -391,3 +391,31 @@ def config_classes(name):
     """(family, n_subcircuits, [class representatives]) of a BASELINE config."""
     family, n = FAMILIES[name]
     return family, n, unique_subcircuits(family, n)
+
+
+def prepare_class_host(job):
+    """Worker-process half of a benchmark / test setup: builds one proving-key class's circuit, runs the host half of
+    the trusted setup (`cp_groth16.setup_host`: toxic waste, QAP evaluation, scalar layout) and generates the
+    assignments of `witness_seeds`.  Pure Python / numpy, no device: safe to run in a spawned process pool BEFORE the
+    parent initialises HIP.  job = (curve, config name, class representative, setup seed bytes, [witness seeds]);
+    returns (class_rep, HostSetup, [(seed, full assignment bytes, stage-0 witness bytes)])."""
+    from .cp_groth16 import SeededRng, setup_host
+    curve, name, rep, seed, witness_seeds = job
+    circ = make_config(curve, name, rep)
+    hs = setup_host(circ, curve, SeededRng(seed))
+    assigns = []
+    for ws in witness_seeds:
+        circ.set_witness_seed(ws)
+        assigns.append((ws, circ.full_assignment_bytes(), circ.stage0_witness_bytes()))
+    return rep, hs, assigns
+
+
+def prepare_classes_host(jobs, max_workers=None):
+    """`prepare_class_host` over several classes in parallel (spawned workers; sequential when there is one)."""
+    if len(jobs) <= 1:
+        return [prepare_class_host(j) for j in jobs]
+    import multiprocessing as mp
+    import os
+    n = min(len(jobs), max_workers or max(1, min(8, (os.cpu_count() or 2) // 2)))
+    with mp.get_context("spawn").Pool(processes=n) as pool:
+        return pool.map(prepare_class_host, jobs)
