@@ -1,6 +1,7 @@
 // Host-compiled view of the PRODUCT's field.cuh / ec.cuh (g++), so the arithmetic the HIP kernels
 // run can be unit-tested against the oracle without a GPU.  Test-only; never part of libhekaton.
 #include "../../hekaton_system_amd/csrc/ec.cuh"
+#include "../../hekaton_system_amd/csrc/pairing.cuh"
 #include <string.h>
 using namespace hk;
 
@@ -40,7 +41,46 @@ static void group_op(int op, const void* a, const void* b, void* out) {
     st(out, ec_to_affine(r));
 }
 
+// Fq12 ops on ark-ordered coordinates.  op 0 mul, 1 sqr, 2 inv, 3 conj, 4 frob1, 5 frob2, 6 frob3, 7 pow_x, 8 final exp
+template <class P>
+static void f12_op(int op, const void* a, const void* b, void* out) {
+    Fp12<P> x, y, r; ld(x, a); if (b) ld(y, b);
+    static Fp12<P> w[PAIR_FEXP_WORDS];
+    switch (op) {
+        case 0: r = f12_mul(x, y); break;
+        case 1: r = f12_sqr(x); break;
+        case 2: r = f12_inv(x); break;
+        case 3: r = f12_conj(x); break;
+        case 4: r = f12_frob<P, 1>(x); break;
+        case 5: r = f12_frob<P, 2>(x); break;
+        case 6: r = f12_frob<P, 3>(x); break;
+        case 7: r = f12_pow_x(x); break;
+        default: r = pair_final_exp<P>(x, w);
+    }
+    st(out, f12_canon(r));
+}
+// prod_i e(g1[i], g2[i]) exactly as the kernels compute it: per-pair Miller values, their product, final exponentiation
+template <class P>
+static void multi_pairing(const void* g1, const void* g2, size_t n, const PairLoop& loop, void* out) {
+    static Fp12<P> w[PAIR_FEXP_WORDS];
+    Fp12<P> acc = f12_one<P>();
+    for (size_t i = 0; i < n; i++) {
+        Affine<Fp<P>> p; Affine<Fp2<P>> q;
+        ld(p, (const char*)g1 + i * sizeof(p)); ld(q, (const char*)g2 + i * sizeof(q));
+        acc = f12_mul(acc, pair_miller_one<P>(p, q, loop));
+    }
+    st(out, f12_canon(pair_final_exp<P>(acc, w)));
+}
+
 extern "C" {
+// curve: 0 bn254, 1 bls12-381
+void shim_f12_op(int curve, int op, const void* a, const void* b, void* out) {
+    if (curve == 0) f12_op<Bn254FqP>(op, a, b, out); else f12_op<Bls381FqP>(op, a, b, out);
+}
+void shim_multi_pairing(int curve, const void* g1, const void* g2, size_t n, void* out) {
+    if (curve == 0) multi_pairing<Bn254FqP>(g1, g2, n, pair_loop_bn254(), out);
+    else multi_pairing<Bls381FqP>(g1, g2, n, pair_loop_bls381(), out);
+}
 // field: 0 bn254 Fr, 1 bn254 Fq, 2 bls Fr, 3 bls Fq, 4 bn254 Fq2, 5 bls Fq2
 void shim_field_op(int field, int op, const void* a, const void* b, void* out) {
     switch (field) {
