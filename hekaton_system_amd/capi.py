@@ -59,7 +59,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_ctx_set_profiling", "hk_ctx_last_timings", "hk_ctx_sizes", "hk_dev_alloc", "hk_dev_free",
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
-           "hk_msm_bases"]
+           "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes"]
 
 _lib = None
 
@@ -100,6 +100,9 @@ def load():
     lib.hk_bases_free.argtypes = [vp]
     lib.hk_bases_free.restype = None
     lib.hk_msm_bases.argtypes = [vp, vp, vp, sz, i, i, vp]
+    lib.hk_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
+    lib.hk_pairing_products.argtypes = [vp, C.POINTER(vp), sz, C.POINTER(vp), sz, sz, vp]
+    lib.hk_ctx_gt_bytes.argtypes = [vp, C.POINTER(sz)]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -175,6 +178,9 @@ class Context:
         fr, fq, g1, g2 = (C.c_size_t() for _ in range(4))
         check(self.lib.hk_ctx_sizes(h, C.byref(fr), C.byref(fq), C.byref(g1), C.byref(g2)), "hk_ctx_sizes")
         self.fr_bytes, self.fq_bytes, self.g1_bytes, self.g2_bytes = fr.value, fq.value, g1.value, g2.value
+        gt = C.c_size_t()
+        check(self.lib.hk_ctx_gt_bytes(h, C.byref(gt)), "hk_ctx_gt_bytes")
+        self.gt_bytes = gt.value
 
     def close(self):
         if self.handle:
@@ -235,6 +241,28 @@ class Context:
         fn = self.lib.hk_scalar_pairing_g1 if group == 1 else self.lib.hk_scalar_pairing_g2
         out = np.zeros(n * pb, dtype=np.uint8)
         check(fn(self.handle, ptr(points), ptr(scalars), n, out.ctypes.data), fn.__name__)
+        return out
+
+    def multi_pairing(self, g1, g2, n=None):
+        """`pairing(left, right)` (distributed-prover/src/pairing_ops.rs:25-29): prod_i e(g1[i], g2[i]) as ark's Fp12
+        bytes (12 Fq, Montgomery)."""
+        n = n if n is not None else len(g1) // self.g1_bytes
+        out = np.zeros(self.gt_bytes, dtype=np.uint8)
+        check(self.lib.hk_multi_pairing(self.handle, ptr(g1) if n else None, ptr(g2) if n else None, n, out.ctypes.data),
+              "hk_multi_pairing")
+        return out
+
+    def pairing_products(self, lhs, rhs, n=None):
+        """Every G1 vector of `lhs` against every G2 vector of `rhs` in one batched launch (the `cross_terms` of
+        aggregation.rs:255-263): returns a (len(lhs), len(rhs), gt_bytes) uint8 array."""
+        n = n if n is not None else len(lhs[0]) // self.g1_bytes
+        keep = [x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8) for x in list(lhs) + list(rhs)]
+        addr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data
+        lp = (C.c_void_p * len(lhs))(*[addr(x) for x in keep[:len(lhs)]])
+        rp = (C.c_void_p * len(rhs))(*[addr(x) for x in keep[len(lhs):]])
+        out = np.zeros((len(lhs), len(rhs), self.gt_bytes), dtype=np.uint8)
+        check(self.lib.hk_pairing_products(self.handle, lp, len(lhs), rp, len(rhs), n, out.ctypes.data),
+              "hk_pairing_products")
         return out
 
     def bases_upload(self, group, bases, n=None):

@@ -247,6 +247,22 @@ hk_status hk_msm_bases(hk_ctx* ctx, const hk_bases* b, const void* scalars, size
     if (!ctx || !b || !out || b->ctx != ctx) return HK_ERR_ARG;
     return ctx->ops->msm_bases(ctx, b, scalars, n_scalars, mont, checked, out);
 }
+hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2,
+                              size_t n_rhs, size_t n, void* gt_out) {
+    if (!ctx || !lhs_g1 || !rhs_g2 || !gt_out) return HK_ERR_ARG;
+    return ctx->ops->pairing_products(ctx, lhs_g1, n_lhs, rhs_g2, n_rhs, n, gt_out);
+}
+hk_status hk_multi_pairing(hk_ctx* ctx, const void* g1, const void* g2, size_t n, void* gt_out) {
+    if (!ctx || !gt_out || (n && (!g1 || !g2))) return HK_ERR_ARG;
+    const void* l[1] = {n ? g1 : (const void*)gt_out};
+    const void* r[1] = {n ? g2 : (const void*)gt_out};
+    return ctx->ops->pairing_products(ctx, l, 1, r, 1, n, gt_out);
+}
+hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt) {
+    if (!ctx || !gt) return HK_ERR_ARG;
+    *gt = ctx->ops->gt_bytes;
+    return HK_OK;
+}
 hk_status hk_field_convert(hk_ctx* ctx, int which, const void* in, void* out, size_t n, int to_mont) {
     if (!ctx || (which != 0 && which != 1) || (n && (!in || !out))) return HK_ERR_ARG;
     return ctx->ops->field_convert(ctx, which, in, out, n, to_mont);

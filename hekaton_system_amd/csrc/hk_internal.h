@@ -109,6 +109,9 @@ struct CurveOps {
     void (*bases_free)(hk_bases*);
     hk_status (*msm_bases)(hk_ctx*, const hk_bases*, const void* scalars, size_t n_scalars, int mont, int checked,
                            void* out);
+    hk_status (*pairing_products)(hk_ctx*, const void* const* lhs, size_t n_lhs, const void* const* rhs, size_t n_rhs,
+                                  size_t n, void* out);
+    size_t gt_bytes;
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

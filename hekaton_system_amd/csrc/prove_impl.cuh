@@ -817,6 +817,44 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
     return group == 1 ? run(Fq()) : run(Fq2());
 }
 
+// ---- multi-pairings (pairing.cuh) ------------------------------------------------------------------------------
+template <class C>
+hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n_lhs, const void* const* rhs,
+                                   size_t n_rhs, size_t n, void* out) {
+    typedef typename Fq::Params P;
+    typedef Fp12<P> GT;
+    size_t count = n_lhs * n_rhs;
+    if (count == 0 || count > 4096) return HK_ERR_ARG;
+    if (n * count >= ((size_t)1 << 31)) return HK_ERR_ARG;
+    if (n == 0) {                                                  // empty product: 1 (final_exponentiation(1) = 1)
+        GT one = f12_one<P>();
+        for (size_t k = 0; k < count; k++) memcpy((char*)out + k * sizeof(GT), &one, sizeof(GT));
+        return HK_OK;
+    }
+    for (size_t a = 0; a < n_lhs; a++) if (!lhs[a]) return HK_ERR_ARG;
+    for (size_t b = 0; b < n_rhs; b++) if (!rhs[b]) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    size_t g1b = sizeof(Affine<Fq>), g2b = sizeof(Affine<Fq2>);
+    size_t need = al256(n_lhs * n * g1b) + al256(n_rhs * n * g2b) + al256(n * count * sizeof(GT)) +
+                  2 * al256(count * sizeof(GT)) + 8192;
+    HK_TRY(L->reserve(need));
+    hipStream_t s = L->stream;
+    Affine<Fq>* d1 = L->alloc_n<Affine<Fq>>(n_lhs * n);
+    Affine<Fq2>* d2 = L->alloc_n<Affine<Fq2>>(n_rhs * n);
+    GT* miller = L->alloc_n<GT>(n * count);
+    GT* prod = L->alloc_n<GT>(count);
+    GT* res = L->alloc_n<GT>(count);
+    if (!d1 || !d2 || !miller || !prod || !res) return HK_ERR_NOMEM;
+    for (size_t a = 0; a < n_lhs; a++) HK_HIP(hipMemcpyAsync(d1 + a * n, lhs[a], n * g1b, h2d_kind(lhs[a]), s));
+    for (size_t b = 0; b < n_rhs; b++) HK_HIP(hipMemcpyAsync(d2 + b * n, rhs[b], n * g2b, h2d_kind(rhs[b]), s));
+    HK_TRY(PairRun<P>::run(s, d1, d2, (u32)n, (u32)n_lhs, (u32)n_rhs, miller, prod, res));
+    HK_HIP(hipMemcpyAsync(out, res, count * sizeof(GT), is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    HK_HIP(hipStreamSynchronize(s));
+    return HK_OK;
+}
+
 // out[i] = in[i] * R (to_mont) or in[i] / R; memory canonical either way
 template <class F>
 __global__ void k_field_convert(const F* __restrict__ in, F* __restrict__ out, size_t n, int to_mont) {

@@ -162,6 +162,21 @@ hk_status hk_fixed_base_g2(hk_ctx* ctx, const void* base, const void* scalars, s
 hk_status hk_scalar_pairing_g1(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
 hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scalars, size_t n, void* out);
 
+/* ---- pairings of the aggregation path -------------------------------------------------------
+ * GT elements cross the ABI as ark's `Fp12`: c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1 - 12 Fq, Montgomery
+ * (hk_ctx_gt_bytes: 384 B on BN254, 576 B on BLS12-381).
+ * hk_multi_pairing: prod_i e(g1[i], g2[i]) = `E::final_exponentiation(E::multi_miller_loop(left, right))` - replaces
+ * `pairing(left, right)` (distributed-prover/src/pairing_ops.rs:9-29; pairs with an infinity member contribute 1,
+ * n = 0 gives 1).  g1 [h|d]: n packed G1 affine; g2 [h|d]: n packed G2 affine; gt_out [h|d].
+ * hk_pairing_products: every lhs vector against every rhs vector in ONE batched launch,
+ * gt_out[a * n_rhs + b] = pairing(lhs_g1[a], rhs_g2[b]) - replaces the 4 x 4 `cross_terms` of
+ * distributed-prover/src/aggregation.rs:255-263 and, with n_lhs = n_rhs = 1, the IPP commitments'
+ * inner products (aggregation.rs:97-103,167-168).  All vectors have n elements. */
+hk_status hk_multi_pairing(hk_ctx* ctx, const void* g1, const void* g2, size_t n, void* gt_out);
+hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2,
+                              size_t n_rhs, size_t n, void* gt_out);
+hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt);
+
 /* ---- MSM over a RESIDENT base set ----------------------------------------------------------------------
  * Bases that are key material (the KZG / commitment-key powers of the aggregator's SRS, any static query) are
  * uploaded once together with their 2^(16 g) multiples, exactly like the proving-key queries; every later MSM over

@@ -141,6 +141,16 @@ class COracle:
             raise ValueError("prove rc=%d" % rc)
         return oa, ob, oc
 
+    def multi_pairing(self, g1, g2, n=None):
+        """`pairing(left, right)` (distributed-prover/src/pairing_ops.rs:25-29), parallel over chunks of 4 pairs like
+        ark's multi_miller_loop; returns the 12 Fq of ark's Fp12 (Montgomery bytes)."""
+        g1 = np.ascontiguousarray(g1, dtype=np.uint8)
+        g2 = np.ascontiguousarray(g2, dtype=np.uint8)
+        n = n if n is not None else len(g1) // self.g1_bytes
+        out = np.zeros(12 * self.fq_bytes, dtype=np.uint8)
+        self.lib.hko_multi_pairing(self.cid, self._p(g1), self._p(g2), C.c_size_t(n), self._p(out))
+        return out
+
     def running_bases(self, group, gen_affine, s0, n):
         gen = np.ascontiguousarray(gen_affine, dtype=np.uint8)
         pb = self.g1_bytes if group == 1 else self.g2_bytes

@@ -1,0 +1,79 @@
+"""GPU: hk_multi_pairing / hk_pairing_products against the tower oracle, bit for bit (GT is a unique Fq12 element:
+ark's tower ordering c0..c11, Montgomery LE), at N in {0, 1, 2, 64} with infinity members on both curves, N = 1024 on
+BN254 through bilinearity (all points are known multiples of the generators, so the product must be e(G,H)^(sum a_i b_i):
+one oracle pairing + one oracle exponentiation instead of 1024 Miller loops), and the 4 x 4 cross-term batch of
+aggregation.rs:255-263."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle.pyref import curve, pairing
+from oracle.pyref.params import CURVES
+from tests.test_pairing_cpu import Enc
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(cname, ctx_bn254, ctx_bls):
+    return ctx_bn254 if cname == "bn254" else ctx_bls
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_multi_pairing_small_bit_exact(cname, ctx_bn254, ctx_bls):
+    ctx = _ctx(cname, ctx_bn254, ctx_bls)
+    cp = CURVES[cname]
+    T = pairing.tower(cname)
+    E = Enc(cp)
+    G1, G2 = curve.G1(cp), curve.G2(cp)
+    rnd = random.Random(77)
+    assert ctx.gt_bytes == 12 * E.nb
+    for n, with_inf in ((0, False), (1, False), (2, False), (64, True)):
+        ps = [G1.mul(cp.g1_gen, rnd.randrange(1, cp.r)) for _ in range(n)]
+        qs = [G2.mul(cp.g2_gen, rnd.randrange(1, cp.r)) for _ in range(n)]
+        if with_inf:
+            ps[3] = None
+            qs[17] = None
+            ps[40], qs[40] = None, None
+        g1 = np.frombuffer(b"".join(E.g1(p) for p in ps), np.uint8) if n else np.zeros(0, np.uint8)
+        g2 = np.frombuffer(b"".join(E.g2(q) for q in qs), np.uint8) if n else np.zeros(0, np.uint8)
+        got = E.f12_dec(ctx.multi_pairing(g1, g2, n=n).tobytes())
+        assert got == T.f12_flat(T.multi_pairing(list(zip(ps, qs)))), (cname, n)
+
+
+def test_multi_pairing_1024_bilinearity_and_cross_terms(ctx_bn254):
+    cname = "bn254"
+    cp = CURVES[cname]
+    T = pairing.tower(cname)
+    E = Enc(cp)
+    from hekaton_system_amd.cp_groth16 import FrCodec
+    fc = FrCodec(cname)
+    rnd = random.Random(4)
+    n = 1024
+    gen1 = np.frombuffer(E.g1(cp.g1_gen), np.uint8)
+    gen2 = np.frombuffer(E.g2(cp.g2_gen), np.uint8)
+    e_gen = T.pairing(cp.g1_gen, cp.g2_gen)
+
+    def vec1():
+        ks = [rnd.randrange(1, cp.r) for _ in range(n)]
+        return ks, ctx_bn254.fixed_base(1, gen1, fc.enc(ks))
+
+    def vec2():
+        ks = [rnd.randrange(1, cp.r) for _ in range(n)]
+        return ks, ctx_bn254.fixed_base(2, gen2, fc.enc(ks))
+
+    a, A = vec1()
+    b, B = vec2()
+    got = E.f12_dec(ctx_bn254.multi_pairing(A, B).tobytes())
+    want = T.f12_pow(e_gen, sum(x * y for x, y in zip(a, b)) % cp.r)
+    assert got == T.f12_flat(want)
+    # 4 x 4 cross terms in one batched call (aggregation.rs:255-263), every entry checked the same way
+    lhs = [(a, A)] + [vec1() for _ in range(3)]
+    rhs = [(b, B)] + [vec2() for _ in range(3)]
+    out = ctx_bn254.pairing_products([v for _, v in lhs], [v for _, v in rhs])
+    assert out.shape == (4, 4, ctx_bn254.gt_bytes)
+    for i, (ka, _) in enumerate(lhs):
+        for j, (kb, _) in enumerate(rhs):
+            want = T.f12_pow(e_gen, sum(x * y for x, y in zip(ka, kb)) % cp.r)
+            assert E.f12_dec(out[i, j].tobytes()) == T.f12_flat(want), (i, j)
+    assert E.f12_dec(out[0, 0].tobytes()) == got

@@ -21,11 +21,13 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# The largest frame any shipped kernel needs is 2.8 KB per lane (12-limb G2 tails).  ROCr sizes a queue's scratch
-# ring for (bytes per lane) x 64 lanes x the device's wave slots; above HSA_SCRATCH_SINGLE_LIMIT (140 MB on this
-# stack) a dispatch takes the slow "use once" path.  4 KB per lane keeps every kernel far from the flat-scratch
-# addressing limits as well (13-bit immediate offsets hold +-4 KB).
-SCRATCH_LIMIT_BYTES = 4096
+# Private memory per lane.  The deepest frames are the serial Fq12 call chains of the pairing kernels (Miller loop ->
+# line product -> Fq12 -> Fq6 -> Fq2 product, each level holding a few 384 / 576-byte temporaries): 5.1 KB per lane
+# on BLS12-381; the MSM tails need up to 2.8 KB.  ROCr sizes a queue's scratch ring for (bytes per lane) x 64 lanes x
+# the device's wave slots and serves a dispatch above HSA_SCRATCH_SINGLE_LIMIT from a use-once allocation, so large
+# frames cost launch latency, not correctness (the round-1 faults were NOT scratch).  8 KB is the
+# fence against an accidental fully-inlined frame.
+SCRATCH_LIMIT_BYTES = 8192
 BRANCH_REACH_BYTES = 32767 * 4      # s_cbranch_*: signed 16-bit dword offset
 
 
