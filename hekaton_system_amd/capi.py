@@ -13,7 +13,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhekaton.so")
+LIB_PATH = os.environ.get("HK_LIB") or os.path.join(_HERE, "lib", "libhekaton.so")    # HK_LIB: experiment builds
 
 HK_BN254, HK_BLS12_381 = 0, 1
 HK_OK, HK_ERR_LEN, HK_ERR_DOMAIN_TOO_LARGE, HK_ERR_DEVICE, HK_ERR_ARG, HK_ERR_NOMEM = range(6)

@@ -9,14 +9,15 @@ namespace hk {
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 inline size_t msm_sort_bytes(const MsmPlan& p) {
-    return al256(4ull * p.NB) * 2 + al256(4ull * (p.NB + 1)) + al256(4ull * ((size_t)p.n * p.W + 1)) + 1024;
+    return al256(4ull * p.NB) * 2 + al256(4ull * (p.NB + 1)) + al256(4ull * ((size_t)p.n * p.W + 1)) +
+           al256(2ull * ((size_t)p.n * p.W + 8)) + 1024;
 }
 template <class F>
 inline size_t msm_run_bytes(const MsmPlan& p0) {
     MsmPlan p = p0;
     msm_set_lanes(p, 4u * 65536u);             // upper bound over the per-flavour lane schedules
     size_t n0 = 2ull * p.T[0], n1 = p.n_levels > 1 ? 2ull * p.T[1] : 2;
-    return al256(sizeof(XYZZ<F>) * p.NB) + al256(4 * n0) + al256(sizeof(XYZZ<F>) * n0) + al256(4 * n1) +
+    return al256(sizeof(XYZZ<F>) * (p.NB + 1)) + al256(4 * n0) + al256(sizeof(XYZZ<F>) * n0) + al256(4 * n1) +
            al256(sizeof(XYZZ<F>) * n1) + al256(sizeof(XYZZ<F>) * p.WP * (p.B / p.K)) +
            al256(sizeof(XYZZ<F>) * p.WP) + 2048;
 }

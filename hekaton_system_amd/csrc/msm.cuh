@@ -28,7 +28,8 @@
 namespace hk {
 
 constexpr int MSM_MAX_LEVELS = 16;
-constexpr u32 MSM_LVL_L = 8;           // entries per lane on levels >= 1 (short dependent chains)
+constexpr u32 MSM_LVL_L = 16;          // entries per lane on levels >= 1: 6 levels for a full 2^18-lane level 0 (8: 10 levels)
+constexpr int MSM_TAIL_THREADS = 256;  // levels whose lane count fits one workgroup run fused in k_msm_accum_tail
 constexpr int MSM_WSUM_THREADS = 256;
 constexpr int MSM_SORT_THREADS = 1024;
 // a sorted entry = sign << 31 | table group << gshift | scalar index, gshift = ceil(log2 n) <= 26 (so no division
@@ -109,7 +110,8 @@ __device__ __forceinline__ int msm_digit(const u32 (&sp)[10], u32 w, u32 c) {
 // ---- counting sort, pass 1: histogram ------------------------------------------------------------
 template <class Fr>
 __global__ void __launch_bounds__(MSM_SORT_THREADS)
-k_msm_hist(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __restrict__ count) {
+k_msm_hist(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __restrict__ count,
+           short* __restrict__ digits) {
     __shared__ u32 h[MSM_LDS_COUNTERS];
     for (u32 b = threadIdx.x; b < p.NB; b += blockDim.x) h[b] = 0;
     __syncthreads();
@@ -121,6 +123,9 @@ k_msm_hist(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __restr
         msm_load_scalar<Fr>(scalars, i, is_mont, p, sp);
         for (u32 w = 0; w < p.W; w++) {
             int d = msm_digit(sp, w, p.c);
+            // the signed digits are computed ONCE per scalar (Montgomery reduction + split) and kept, window-major,
+            // for the two passes of k_msm_scatter: 2 bytes per digit, coalesced across the lanes of a wave
+            digits[(size_t)w * p.n + i] = (short)d;
             if (d != 0) {
                 u32 mag = d < 0 ? (u32)(-d) : (u32)d;
                 atomicAdd(&h[(w % p.WP) * p.B + mag - 1], 1u);
@@ -162,11 +167,12 @@ k_msm_scan(const u32* __restrict__ count, u32* __restrict__ start, u32* __restri
 }
 
 // ---- counting sort, pass 2: scatter entry ids ----------------------------------------------------------
-// entry = sign << 31 | group << p.gshift | i
+// entry = sign << 31 | group << p.gshift | i.   Reads the digits k_msm_hist stored (c <= 16: a digit is an int16;
+// -2^15 is the one value whose magnitude needs the unsigned form).
+__device__ __forceinline__ u32 msm_mag(int d) { return d < 0 ? (u32)(-d) : (u32)d; }
 template <class Fr>
 __global__ void __launch_bounds__(MSM_SORT_THREADS)
-k_msm_scatter(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __restrict__ cursor,
-              u32* __restrict__ sorted) {
+k_msm_scatter(const short* __restrict__ digits, MsmPlan p, u32* __restrict__ cursor, u32* __restrict__ sorted) {
     __shared__ u32 h[MSM_LDS_COUNTERS];
     for (u32 b = threadIdx.x; b < p.NB; b += blockDim.x) h[b] = 0;
     __syncthreads();
@@ -174,14 +180,9 @@ k_msm_scatter(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __re
     for (u32 k = threadIdx.x; k < p.chunk; k += blockDim.x) {
         size_t i = base + k;
         if (i >= p.n) break;
-        u32 sp[10];
-        msm_load_scalar<Fr>(scalars, i, is_mont, p, sp);
         for (u32 w = 0; w < p.W; w++) {
-            int d = msm_digit(sp, w, p.c);
-            if (d != 0) {
-                u32 mag = d < 0 ? (u32)(-d) : (u32)d;
-                atomicAdd(&h[(w % p.WP) * p.B + mag - 1], 1u);
-            }
+            int d = digits[(size_t)w * p.n + i];
+            if (d != 0) atomicAdd(&h[(w % p.WP) * p.B + msm_mag(d) - 1], 1u);
         }
     }
     __syncthreads();
@@ -194,13 +195,10 @@ k_msm_scatter(const u32* __restrict__ scalars, int is_mont, MsmPlan p, u32* __re
     for (u32 k = threadIdx.x; k < p.chunk; k += blockDim.x) {
         size_t i = base + k;
         if (i >= p.n) break;
-        u32 sp[10];
-        msm_load_scalar<Fr>(scalars, i, is_mont, p, sp);
         for (u32 w = 0; w < p.W; w++) {
-            int d = msm_digit(sp, w, p.c);
+            int d = digits[(size_t)w * p.n + i];
             if (d != 0) {
-                u32 mag = d < 0 ? (u32)(-d) : (u32)d;
-                u32 pos = atomicAdd(&h[(w % p.WP) * p.B + mag - 1], 1u);
+                u32 pos = atomicAdd(&h[(w % p.WP) * p.B + msm_mag(d) - 1], 1u);
                 sorted[pos] = ((w / p.WP) << p.gshift) | (u32)i | (d < 0 ? 0x80000000u : 0u);
             }
         }
@@ -269,7 +267,10 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
 template <class F> struct AccumInlineCorner { static constexpr bool value = F::Params::N <= 8; };
 template <class P> struct AccumInlineCorner<Fp<P>> { static constexpr bool value = true; };
 template <class F> struct AccumOcc { static constexpr int waves = 1; };
-template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? 4 : 3; };
+#ifndef HK_ACCUM_WAVES_G1_8LIMB
+#define HK_ACCUM_WAVES_G1_8LIMB 4      // build-time experiment knob (make EXTRA=-DHK_ACCUM_WAVES_G1_8LIMB=5)
+#endif
+template <class P> struct AccumOcc<Fp<P>> { static constexpr int waves = P::N <= 8 ? HK_ACCUM_WAVES_G1_8LIMB : 3; };
 template <class P> struct AccumOcc<Fp2<P>> { static constexpr int waves = P::N <= 8 ? 2 : 1; };   // 207 VGPRs with the asm add/sub
 
 // ---- level 0: equal slices of the sorted entry list, mixed adds into registers ---------------------
@@ -326,14 +327,10 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
 
 // ---- levels >= 1: segmented reduction of boundary partials ---------------------------------------------
 template <class F>
-__global__ void __launch_bounds__(64)
-k_msm_accum_lvl(int level, const u32* __restrict__ keys_in, const XYZZ<F>* __restrict__ pts_in,
-                const u32* __restrict__ start, MsmPlan p, XYZZ<F>* __restrict__ buckets,
-                u32* __restrict__ keys_out, XYZZ<F>* __restrict__ pts_out) {
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 E = start[p.NB];
-    LevelInfo li = msm_level_info(p, E, level);
-    if (t >= li.active) return;
+__device__ __forceinline__ void msm_accum_level(int level, u32 t, const LevelInfo& li, const u32* __restrict__ keys_in,
+                                                const XYZZ<F>* __restrict__ pts_in, const MsmPlan& p,
+                                                XYZZ<F>* __restrict__ buckets, u32* __restrict__ keys_out,
+                                                XYZZ<F>* __restrict__ pts_out) {
     u32 pos = t * li.L;
     u32 end = min(pos + li.L, li.count);
     u32 key = keys_in[pos];
@@ -352,7 +349,7 @@ k_msm_accum_lvl(int level, const u32* __restrict__ keys_in, const XYZZ<F>* __res
             key = kk;
         }
         XYZZ<F> q = ld_vec(&pts_in[pos]);
-        if (!q.is_inf()) acc = ec_add(acc, q);
+        if (!q.is_inf()) acc = ec_add_ni(acc, q);
     }
     bool tail_partial = end < li.count && keys_in[end] == key;
     XYZZ<F> tail = XYZZ<F>::inf();
@@ -364,6 +361,37 @@ k_msm_accum_lvl(int level, const u32* __restrict__ keys_in, const XYZZ<F>* __res
         keys_out[2 * t + 1] = key;
         st_vec(&pts_out[2 * t], head);
         st_vec(&pts_out[2 * t + 1], tail);
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(64)
+k_msm_accum_lvl(int level, const u32* __restrict__ keys_in, const XYZZ<F>* __restrict__ pts_in,
+                const u32* __restrict__ start, MsmPlan p, XYZZ<F>* __restrict__ buckets,
+                u32* __restrict__ keys_out, XYZZ<F>* __restrict__ pts_out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 E = start[p.NB];
+    LevelInfo li = msm_level_info(p, E, level);
+    if (t >= li.active) return;
+    msm_accum_level<F>(level, t, li, keys_in, pts_in, p, buckets, keys_out, pts_out);
+}
+
+// every level from `level0` on (each at most MSM_TAIL_THREADS lanes wide) in ONE workgroup, ping-ponging the two
+// partial buffers with a workgroup barrier between levels: replaces the last 3 launches of the level chain
+template <class F>
+__global__ void __launch_bounds__(MSM_TAIL_THREADS)
+k_msm_accum_tail(int level0, u32* __restrict__ keys0, XYZZ<F>* __restrict__ pts0, u32* __restrict__ keys1,
+                 XYZZ<F>* __restrict__ pts1, const u32* __restrict__ start, MsmPlan p, XYZZ<F>* __restrict__ buckets) {
+    u32 t = threadIdx.x;
+    u32 E = start[p.NB];
+    for (int level = level0; level < (int)p.n_levels; level++) {
+        LevelInfo li = msm_level_info(p, E, level);
+        bool in0 = ((level - 1) & 1) == 0;           // level k reads buffer (k-1)&1 and writes buffer k&1
+        if (t < li.active)
+            msm_accum_level<F>(level, t, li, in0 ? keys0 : keys1, in0 ? pts0 : pts1, p, buckets, in0 ? keys1 : keys0,
+                               in0 ? pts1 : pts0);
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -393,6 +421,68 @@ k_msm_bucket_reduce(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __r
         tot = ec_add_ni(tot, acc);
     }
     st_vec(&out[t], tot);
+}
+
+// WP == 1 (every table-backed MSM): bucket reduction, the sum over lanes and the final result in ONE launch.
+// Every workgroup reduces its lanes' weighted bucket sums in LDS and publishes one partial; the workgroup that
+// takes the last ticket adds the partials.  `ticket` is zeroed together with the buckets (it sits right behind them).
+constexpr int MSM_REDUCE_THREADS = 128;
+template <class F>
+__global__ void __launch_bounds__(MSM_REDUCE_THREADS)
+k_msm_reduce_fused(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __restrict__ partial,
+                   u32* __restrict__ ticket, XYZZ<F>* __restrict__ res) {
+    __shared__ XYZZ<F> sh[MSM_REDUCE_THREADS];
+    __shared__ u32 last;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 J = p.B / p.K;
+    XYZZ<F> tot = XYZZ<F>::inf();
+    if (t < J) {
+        const XYZZ<F>* bk = buckets + (size_t)t * p.K;
+        XYZZ<F> run = XYZZ<F>::inf();
+        for (int b = (int)p.K - 1; b >= 0; b--) {
+            XYZZ<F> q = ld_vec(&bk[b]);
+            run = ec_add_ni(run, q);
+            tot = ec_add_ni(tot, run);
+        }
+        u32 wgt = t * p.K;
+        if (wgt && !run.is_inf()) {
+            XYZZ<F> acc = XYZZ<F>::inf();
+            for (int bit = 31 - __clz(wgt); bit >= 0; bit--) {
+                acc = ec_dbl_ni(acc);
+                if ((wgt >> bit) & 1) acc = ec_add_ni(acc, run);
+            }
+            tot = ec_add_ni(tot, acc);
+        }
+    }
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (u32 off = MSM_REDUCE_THREADS / 2; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            XYZZ<F> a = sh[threadIdx.x], b = sh[threadIdx.x + off];
+            sh[threadIdx.x] = ec_add_ni(a, b);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st_vec(&partial[blockIdx.x], sh[0]);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (u32 j = threadIdx.x; j < gridDim.x; j += MSM_REDUCE_THREADS) acc = ec_add_ni(acc, ld_vec(&partial[j]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 off = MSM_REDUCE_THREADS / 2; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            XYZZ<F> a = sh[threadIdx.x], b = sh[threadIdx.x + off];
+            sh[threadIdx.x] = ec_add_ni(a, b);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_vec(res, sh[0]);
 }
 
 // one workgroup per window: LDS tree over the J lane results

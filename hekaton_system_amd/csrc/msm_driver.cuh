@@ -13,6 +13,7 @@ struct SortBufs {        // device buffers produced by the counting sort
     u32* start;          // [NB + 1]   start[NB] = number of non-zero digits E
     u32* cursor;         // [NB]
     u32* sorted;         // [n * W]    entry ids grouped by bucket
+    short* digits;       // [W][n]     signed window digits, written once by k_msm_hist
 };
 
 template <class Fr>

@@ -23,24 +23,25 @@ hk_status MsmSort<Fr>::alloc(Lane* L, const MsmPlan& p, SortBufs* out) {
     out->start = L->alloc_n<u32>(p.NB + 1);
     out->cursor = L->alloc_n<u32>(p.NB);
     out->sorted = L->alloc_n<u32>((size_t)p.n * p.W + 1);
-    if (!out->count || !out->start || !out->cursor || !out->sorted) return HK_ERR_NOMEM;
+    out->digits = L->alloc_n<short>((size_t)p.n * p.W + 8);
+    if (!out->count || !out->start || !out->cursor || !out->sorted || !out->digits) return HK_ERR_NOMEM;
     return HK_OK;
 }
 
 template <class Fr>
 hk_status MsmSort<Fr>::run(hipStream_t s, const MsmPlan& p, const u32* scalars_d, int is_mont,
                            const SortBufs& sb) {
-    if (p.NB > (u32)MSM_LDS_COUNTERS) return HK_ERR_ARG;
+    if (p.NB > (u32)MSM_LDS_COUNTERS || p.c > 16) return HK_ERR_ARG;       // digits are stored as int16
     HK_HIP(hipMemsetAsync(sb.count, 0, sizeof(u32) * p.NB, s));
     u32 blocks = (p.n + p.chunk - 1) / p.chunk;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL((k_msm_hist<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, s,
-                       scalars_d, is_mont, p, sb.count);
+                       scalars_d, is_mont, p, sb.count, sb.digits);
     HK_DBG(s, "k_msm_hist");
     hipLaunchKernelGGL((k_msm_scan<0>), dim3(1), dim3(1024), 0, s, sb.count, sb.start, sb.cursor, p.NB);
     HK_DBG(s, "k_msm_scan");
     hipLaunchKernelGGL((k_msm_scatter<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, s,
-                       scalars_d, is_mont, p, sb.cursor, sb.sorted);
+                       (const short*)sb.digits, p, sb.cursor, sb.sorted);
     HK_DBG(s, "k_msm_scatter");
     HK_HIP(hipGetLastError());
     return HK_OK;
@@ -58,7 +59,7 @@ static inline MsmPlan msm_lane_plan(const MsmPlan& p0) {
 template <class F>
 hk_status MsmRun<F>::alloc(Lane* L, const MsmPlan& p0, Bufs* out) {
     const MsmPlan p = msm_lane_plan<F>(p0);
-    out->buckets = L->alloc_n<XYZZ<F>>(p.NB);
+    out->buckets = L->alloc_n<XYZZ<F>>(p.NB + 1);          // + one slot: the reduction ticket, zeroed with the buckets
     size_t n0 = 2ull * p.T[0];
     size_t n1 = p.n_levels > 1 ? 2ull * p.T[1] : 2;
     out->pkeys[0] = L->alloc_n<u32>(n0);
@@ -78,7 +79,8 @@ hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p0, const Affine<F>* tabl
                          const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
                          hipEvent_t ev0, hipEvent_t ev1) {
     const MsmPlan p = msm_lane_plan<F>(p0);
-    HK_HIP(hipMemsetAsync(b.buckets, 0, sizeof(XYZZ<F>) * p.NB, s));
+    HK_HIP(hipMemsetAsync(b.buckets, 0, sizeof(XYZZ<F>) * (p.NB + 1), s));
+    u32* ticket = reinterpret_cast<u32*>(b.buckets + p.NB);
     // with profiling on, ev0/ev1 take the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), so
     // the figure agrees with rocprofv3's kernel trace even when other lanes share the hardware queues
     if (ev0 && ev1)
@@ -88,20 +90,33 @@ hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p0, const Affine<F>* tabl
         hipLaunchKernelGGL((k_msm_accum0<F>), dim3((p.T[0] + 63) / 64), dim3(64), 0, s,
                            table, n_bases, idx_off, sb.sorted, sb.start, p, b.buckets, b.pkeys[0], b.ppts[0]);
     HK_DBG(s, "k_msm_accum0");
-    for (u32 k = 1; k < p.n_levels; k++) {
+    u32 k = 1;
+    for (; k < p.n_levels && p.T[k] > (u32)MSM_TAIL_THREADS; k++) {
         int in = (k - 1) & 1, out = k & 1;
         hipLaunchKernelGGL((k_msm_accum_lvl<F>), dim3((p.T[k] + 63) / 64), dim3(64), 0, s,
                            (int)k, b.pkeys[in], b.ppts[in], sb.start, p, b.buckets, b.pkeys[out], b.ppts[out]);
         HK_DBG(s, "k_msm_accum_lvl");
     }
+    if (k < p.n_levels) {                                   // the remaining levels fit one workgroup each: one launch
+        hipLaunchKernelGGL((k_msm_accum_tail<F>), dim3(1), dim3(MSM_TAIL_THREADS), 0, s, (int)k, b.pkeys[0], b.ppts[0],
+                           b.pkeys[1], b.ppts[1], sb.start, p, b.buckets);
+        HK_DBG(s, "k_msm_accum_tail");
+    }
     u32 J = p.B / p.K;
-    hipLaunchKernelGGL((k_msm_bucket_reduce<F>), dim3((p.WP * J + 63) / 64), dim3(64), 0, s,
-                       b.buckets, p, b.red);
-    HK_DBG(s, "k_msm_bucket_reduce");
-    hipLaunchKernelGGL((k_msm_window_sum<F>), dim3(p.WP), dim3(MSM_WSUM_THREADS), 0, s, b.red, p, b.wsum);
-    HK_DBG(s, "k_msm_window_sum");
-    hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, s, b.wsum, p, result_d);
-    HK_DBG(s, "k_msm_final");
+    if (p.WP == 1) {
+        u32 blocks = (J + MSM_REDUCE_THREADS - 1) / MSM_REDUCE_THREADS;
+        hipLaunchKernelGGL((k_msm_reduce_fused<F>), dim3(blocks), dim3(MSM_REDUCE_THREADS), 0, s, b.buckets, p, b.red,
+                           ticket, result_d);
+        HK_DBG(s, "k_msm_reduce_fused");
+    } else {
+        hipLaunchKernelGGL((k_msm_bucket_reduce<F>), dim3((p.WP * J + 63) / 64), dim3(64), 0, s,
+                           b.buckets, p, b.red);
+        HK_DBG(s, "k_msm_bucket_reduce");
+        hipLaunchKernelGGL((k_msm_window_sum<F>), dim3(p.WP), dim3(MSM_WSUM_THREADS), 0, s, b.red, p, b.wsum);
+        HK_DBG(s, "k_msm_window_sum");
+        hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, s, b.wsum, p, result_d);
+        HK_DBG(s, "k_msm_final");
+    }
     HK_HIP(hipGetLastError());
     return HK_OK;
 }

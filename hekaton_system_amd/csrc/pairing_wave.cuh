@@ -1,0 +1,293 @@
+// pairing_wave.cuh — WAVE-PARALLEL Fq12 arithmetic: one 64-lane wavefront multiplies two Fq12 values.
+//
+// A pairing's critical path (Miller accumulation, final exponentiation) is a chain of ~500 dependent Fq12 products;
+// on one lane each costs 54 field products back to back (~35 us).  Here the three-level Karatsuba of the tower is laid
+// across the wave instead: lane l < 54 forms its two operands (sums of <= 8 coefficients, PRE tables), does ONE field
+// product, and the 12 output coefficients are integer combinations of the 54 products (POST tables: multipliers
+// 1, 8, 9, 10 on BN254, 1, 2 on BLS12-381, evaluated Horner-wise over their bits; each output split over 4 lanes).
+// Values live in LDS as 13 Fq (12 coefficients, ark order, + a zero the operand tables pad with), lazily reduced;
+// a workgroup IS one wave, so the barriers between the phases are wave-local.
+// Tables: gen_tower_params.py (derived symbolically from the tower formulas and self-checked numerically).
+#pragma once
+#include "pairing.cuh"
+#include "hk_wave_f12.h"
+
+namespace hk {
+
+#if defined(__HIPCC__)
+
+template <class P> struct WaveTab;
+#define HK_DEFINE_WAVETAB(FQP, PRE)                                                                      \
+    static __device__ const unsigned char PRE##_pre_cnt[54] = PRE##_PRE_CNT;                             \
+    static __device__ const unsigned char PRE##_pre_idx[54][8] = PRE##_PRE_IDX;                          \
+    static __device__ const unsigned char PRE##_post[48][PRE##_POST_LEN] = PRE##_POST;                   \
+    static __device__ const u32 PRE##_frob[3][6][2][FQP::N] = PRE##_FROB;                                \
+    template <> struct WaveTab<FQP> {                                                                    \
+        static constexpr int NLEVELS = PRE##_NLEVELS;                                                    \
+        static constexpr int POST_LEN = PRE##_POST_LEN;                                                  \
+        static __device__ __forceinline__ u32 pre_cnt(u32 l) { return PRE##_pre_cnt[l]; }               \
+        static __device__ __forceinline__ const unsigned char* pre_idx(u32 l) { return PRE##_pre_idx[l]; } \
+        static __device__ __forceinline__ const unsigned char* post(u32 l) { return PRE##_post[l]; }     \
+        static __device__ __forceinline__ const u32* frob(int k, u32 j, u32 c) { return PRE##_frob[k - 1][j][c]; } \
+    };
+HK_DEFINE_WAVETAB(Bn254FqP, HK_BN254_WV)
+HK_DEFINE_WAVETAB(Bls381FqP, HK_BLS12_381_WV)
+
+constexpr int WV_SLOT = 13;            // Fq per value: 12 coefficients + one zero
+
+// LDS work area of one wave
+template <class P>
+struct WaveArea {
+    Fp<P> prod[54];
+    Fp<P> part[48];
+};
+
+template <class P>
+struct WaveF12 {
+    typedef Fp<P> Fq;
+    typedef WaveTab<P> T;
+
+    static __device__ __forceinline__ void sync() { __syncthreads(); }
+
+    // dst = a * b   (dst may alias a or b)
+    static __device__ __noinline__ void mul(Fq* dst, const Fq* a, const Fq* b, WaveArea<P>* w) {
+        u32 lane = threadIdx.x;
+        if (lane < 54) {
+            u32 cnt = T::pre_cnt(lane);
+            const unsigned char* ix = T::pre_idx(lane);
+            Fq x = a[ix[0]], y = b[ix[0]];
+            for (u32 j = 1; j < cnt; j++) {
+                x = Fq::add(x, a[ix[j]]);
+                y = Fq::add(y, b[ix[j]]);
+            }
+            w->prod[lane] = Fq::mul(x, y);
+        }
+        sync();
+        if (lane < 48) {
+            const unsigned char* s = T::post(lane);
+            Fq acc = Fq::zero();
+            u32 pos = 0;
+            for (int lev = 0; lev < T::NLEVELS; lev++) {
+                if (lev) acc = Fq::dbl(acc);
+                u32 cnt = s[pos++];
+                for (u32 e = 0; e < cnt; e++) {
+                    u32 code = s[pos + e];
+                    Fq v = w->prod[code & 0x7f];
+                    acc = (code & 0x80) ? Fq::sub(acc, v) : Fq::add(acc, v);
+                }
+                pos += cnt;
+            }
+            w->part[lane] = acc;
+        }
+        sync();
+        if (lane < 12) {
+            Fq r = Fq::add(Fq::add(w->part[4 * lane], w->part[4 * lane + 1]),
+                           Fq::add(w->part[4 * lane + 2], w->part[4 * lane + 3]));
+            dst[lane] = r;
+        }
+        if (lane == 12) dst[12] = Fq::zero();
+        sync();
+    }
+    static __device__ __forceinline__ void sqr(Fq* dst, const Fq* a, WaveArea<P>* w) { mul(dst, a, a, w); }
+
+    static __device__ __forceinline__ void copy(Fq* dst, const Fq* a) {
+        u32 lane = threadIdx.x;
+        Fq v;
+        if (lane < 13) v = a[lane];
+        sync();
+        if (lane < 13) dst[lane] = v;
+        sync();
+    }
+    static __device__ __forceinline__ void set_one(Fq* dst) {
+        u32 lane = threadIdx.x;
+        if (lane < 13) dst[lane] = lane == 0 ? Fq::one() : Fq::zero();
+        sync();
+    }
+    // dst = conj(a) = a^(q^6)
+    static __device__ __forceinline__ void conj(Fq* dst, const Fq* a) {
+        u32 lane = threadIdx.x;
+        Fq v;
+        if (lane < 13) { v = a[lane]; if (lane >= 6 && lane < 12) v = Fq::neg(v); }
+        sync();
+        if (lane < 13) dst[lane] = v;
+        sync();
+    }
+    // dst = a^(q^K), K = 1..3: lane 2j + c computes component c of (Fq2 coefficient j, conjugated when K is odd) * const_j
+    template <int K>
+    static __device__ __noinline__ void frob(Fq* dst, const Fq* a) {
+        u32 lane = threadIdx.x;
+        Fq r;
+        if (lane < 12) {
+            u32 j = lane >> 1, c = lane & 1;
+            Fq x0 = a[2 * j], x1 = a[2 * j + 1];
+            if (K & 1) x1 = Fq::neg(x1);
+            Fq k0, k1;
+            const u32* p0 = T::frob(K, j, 0);
+            const u32* p1 = T::frob(K, j, 1);
+            for (int i = 0; i < P::N; i++) { k0.v[i] = p0[i]; k1.v[i] = p1[i]; }
+            r = c == 0 ? Fq::sub(Fq::mul(x0, k0), Fq::mul(x1, k1)) : Fq::add(Fq::mul(x0, k1), Fq::mul(x1, k0));
+        }
+        sync();
+        if (lane < 12) dst[lane] = r;
+        if (lane == 12) dst[12] = Fq::zero();
+        sync();
+    }
+    // slot <-> tower struct (lane 0 only; used for the one inversion of the final exponentiation)
+    static __device__ __forceinline__ Fp12<P> load_tower(const Fq* a) {
+        Fp12<P> f;
+        f.c0.c0.c0 = a[0]; f.c0.c0.c1 = a[1]; f.c0.c1.c0 = a[2]; f.c0.c1.c1 = a[3]; f.c0.c2.c0 = a[4]; f.c0.c2.c1 = a[5];
+        f.c1.c0.c0 = a[6]; f.c1.c0.c1 = a[7]; f.c1.c1.c0 = a[8]; f.c1.c1.c1 = a[9]; f.c1.c2.c0 = a[10]; f.c1.c2.c1 = a[11];
+        return f;
+    }
+    static __device__ __forceinline__ void store_tower(Fq* a, const Fp12<P>& f) {
+        a[0] = f.c0.c0.c0; a[1] = f.c0.c0.c1; a[2] = f.c0.c1.c0; a[3] = f.c0.c1.c1; a[4] = f.c0.c2.c0; a[5] = f.c0.c2.c1;
+        a[6] = f.c1.c0.c0; a[7] = f.c1.c0.c1; a[8] = f.c1.c1.c0; a[9] = f.c1.c1.c1; a[10] = f.c1.c2.c0; a[11] = f.c1.c2.c1;
+        a[12] = Fq::zero();
+    }
+    static __device__ __noinline__ void inv(Fq* dst, const Fq* a) {
+        if (threadIdx.x == 0) {
+            Fp12<P> f = f12_inv(load_tower(a));
+            store_tower(dst, f);
+        }
+        sync();
+    }
+    // dst = a^X (X = the curve parameter); t: one scratch slot.  dst, a, t distinct.
+    static __device__ __noinline__ void pow_x(Fq* dst, const Fq* a, WaveArea<P>* w) {
+        const u64 x = TowerParams<P>::X;
+        copy(dst, a);
+        int top = 63;
+        while (!((x >> top) & 1)) top--;
+        for (int bit = top - 1; bit >= 0; bit--) {
+            sqr(dst, dst, w);
+            if ((x >> bit) & 1) mul(dst, dst, a, w);
+        }
+    }
+    static __device__ __forceinline__ void exp_by_x(Fq* dst, const Fq* a, WaveArea<P>* w) {          // bls12 exp_by_x
+        pow_x(dst, a, w);
+        if (TowerParams<P>::X_IS_NEGATIVE) conj(dst, dst);
+    }
+    static __device__ __forceinline__ void exp_by_neg_x(Fq* dst, const Fq* a, WaveArea<P>* w) {      // bn exp_by_neg_x
+        pow_x(dst, a, w);
+        if (!TowerParams<P>::X_IS_NEGATIVE) conj(dst, dst);
+    }
+
+    // s: >= 10 slots; s[0] holds f on entry and the result on exit (same chains as pair_final_exp)
+    static __device__ __noinline__ void final_exp(Fq* s, WaveArea<P>* w) {
+        typedef TowerParams<P> TP;
+        auto S = [&](int i) { return s + i * WV_SLOT; };
+        Fq *r = S(0), *t = S(7), *u = S(8);
+        inv(t, r);                       // f^-1
+        conj(u, r);
+        mul(r, u, t, w);                 // f^(q^6 - 1)
+        frob<2>(t, r);
+        mul(r, t, r, w);                 // r = f^((q^6 - 1)(q^2 + 1))
+        if (TP::TWIST_IS_D) {
+            Fq *y1 = S(1), *y3 = S(2), *y4 = S(3), *y6 = S(4), *y8 = S(5), *y9 = S(6);
+            exp_by_neg_x(t, r, w);       // y0
+            sqr(y1, t, w);
+            sqr(t, y1, w);               // y2
+            mul(y3, t, y1, w);
+            exp_by_neg_x(y4, y3, w);
+            sqr(t, y4, w);               // y5
+            exp_by_neg_x(y6, t, w);
+            conj(y3, y3);
+            conj(y6, y6);
+            mul(t, y6, y4, w);           // y7
+            mul(y8, t, y3, w);
+            mul(y9, y8, y1, w);
+            mul(t, y8, y4, w);           // y10
+            mul(t, t, r, w);             // y11
+            frob<1>(u, y9);              // y12
+            mul(t, u, t, w);             // y13
+            frob<2>(y8, y8);
+            mul(t, y8, t, w);            // y14
+            conj(r, r);
+            mul(u, r, y9, w);
+            frob<3>(u, u);               // y15
+            mul(r, u, t, w);
+        } else {
+            Fq *y0 = S(1), *y1 = S(2), *y2 = S(3);
+            sqr(y0, r, w);
+            exp_by_x(y1, r, w);
+            conj(y2, r);
+            mul(y1, y1, y2, w);
+            exp_by_x(y2, y1, w);
+            conj(y1, y1);
+            mul(y1, y1, y2, w);
+            exp_by_x(y2, y1, w);
+            frob<1>(y1, y1);
+            mul(y1, y1, y2, w);
+            mul(r, r, y0, w);
+            exp_by_x(y0, y1, w);
+            exp_by_x(y2, y0, w);
+            frob<2>(y0, y1);
+            conj(y1, y1);
+            mul(y1, y1, y2, w);
+            mul(y1, y1, y0, w);
+            mul(r, r, y1, w);
+        }
+    }
+    // global (canonical, 12 Fq) <-> slot
+    static __device__ __forceinline__ void load(Fq* dst, const Fp12<P>* g) {
+        u32 lane = threadIdx.x;
+        const Fq* src = reinterpret_cast<const Fq*>(g);
+        if (lane < 12) dst[lane] = ld_vec(&src[lane]);
+        if (lane == 12) dst[12] = Fq::zero();
+        sync();
+    }
+    static __device__ __forceinline__ void store(Fp12<P>* g, const Fq* a) {
+        u32 lane = threadIdx.x;
+        Fq* d = reinterpret_cast<Fq*>(g);
+        if (lane < 12) st_vec(&d[lane], a[lane]);        // canonicalises
+        sync();
+    }
+};
+
+constexpr int WV_FINISH_SLOTS = 12;
+
+// One wave per product: the product of its n Miller values (each lane-group of the wave takes a strided share through
+// the wave multiplier: acc *= in[i]), then the final exponentiation.  in: [count][n] canonical Fq12; out: [count].
+template <class P>
+__global__ void __launch_bounds__(64)
+k_pair_finish(const Fp12<P>* __restrict__ in, u32 n, Fp12<P>* __restrict__ out) {
+    extern __shared__ unsigned char pair_lds[];
+    typedef WaveF12<P> W;
+    typedef Fp<P> Fq;
+    WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
+    Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    const Fp12<P>* src = in + (size_t)blockIdx.x * n;
+    Fq* acc = s;
+    Fq* cur = s + 9 * WV_SLOT;
+    W::load(acc, &src[0]);
+    for (u32 i = 1; i < n; i++) {
+        W::load(cur, &src[i]);
+        W::mul(acc, acc, cur, w);
+    }
+    W::final_exp(s, w);
+    W::store(&out[blockIdx.x], acc);
+}
+
+// Tree level of the Miller-value product: wave g multiplies in[g*c .. min((g+1)*c, n)) of its product -> out[g].
+// grid = (groups, count); in: [count][n], out: [count][groups].
+template <class P>
+__global__ void __launch_bounds__(64)
+k_pair_tree(const Fp12<P>* __restrict__ in, u32 n, u32 c, Fp12<P>* __restrict__ out) {
+    extern __shared__ unsigned char pair_lds[];
+    typedef WaveF12<P> W;
+    typedef Fp<P> Fq;
+    WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
+    Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    Fq *acc = s, *cur = s + WV_SLOT;
+    u32 lo = blockIdx.x * c, hi = min(lo + c, n);
+    const Fp12<P>* src = in + (size_t)blockIdx.y * n;
+    W::load(acc, &src[lo]);
+    for (u32 i = lo + 1; i < hi; i++) {
+        W::load(cur, &src[i]);
+        W::mul(acc, acc, cur, w);
+    }
+    W::store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace hk

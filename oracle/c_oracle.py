@@ -151,6 +151,15 @@ class COracle:
         self.lib.hko_multi_pairing(self.cid, self._p(g1), self._p(g2), C.c_size_t(n), self._p(out))
         return out
 
+    def scalar_mul_each(self, group, points, scalars):
+        """`scalar_pairing` (distributed-prover/src/pairing_ops.rs:32-39): out[i] = scalars[i] * points[i]."""
+        points = np.ascontiguousarray(points, dtype=np.uint8)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+        n = len(scalars) // self.fr_bytes
+        out = np.zeros(len(points), dtype=np.uint8)
+        self.lib.hko_scalar_mul_each(self.cid, group, self._p(points), self._p(scalars), C.c_size_t(n), self._p(out))
+        return out
+
     def running_bases(self, group, gen_affine, s0, n):
         gen = np.ascontiguousarray(gen_affine, dtype=np.uint8)
         pb = self.g1_bytes if group == 1 else self.g2_bytes

@@ -69,3 +69,28 @@ def test_groth16_golden(co):
                           gu.hb(case["s_mont"]), kap)
         assert (a.tobytes().hex(), b.tobytes().hex(), c.tobytes().hex()) == \
                (case["proof"]["a"], case["proof"]["b"], case["proof"]["c"]), case["label"]
+
+
+def test_pairing_matches_the_tower_oracle(co):
+    """hko_multi_pairing (ark's chunked multi_miller_loop + final exponentiation, 64-bit limbs) against
+    oracle/pyref/pairing.py on 0, 1, 5 (one chunk + one pair, with infinity members) and 9 pairs."""
+    import random
+    from oracle.pyref import curve, pairing
+    from oracle.pyref.params import CURVES
+    from tests.test_pairing_cpu import Enc
+    o, name = co
+    cp = CURVES[name]
+    T = pairing.tower(name)
+    E = Enc(cp)
+    G1, G2 = curve.G1(cp), curve.G2(cp)
+    rnd = random.Random(31)
+    for n, with_inf in ((0, False), (1, False), (5, True), (9, False)):
+        ps = [G1.mul(cp.g1_gen, rnd.randrange(1, cp.r)) for _ in range(n)]
+        qs = [G2.mul(cp.g2_gen, rnd.randrange(1, cp.r)) for _ in range(n)]
+        if with_inf:
+            ps[0] = None
+            qs[4] = None
+        g1 = np.frombuffer(b"".join(E.g1(p) for p in ps) or bytes(2 * E.nb), np.uint8)
+        g2 = np.frombuffer(b"".join(E.g2(q) for q in qs) or bytes(4 * E.nb), np.uint8)
+        got = E.f12_dec(o.multi_pairing(g1, g2, n=n).tobytes())
+        assert got == T.f12_flat(T.multi_pairing(list(zip(ps, qs)))), (name, n)

@@ -30,7 +30,47 @@ def main():
     except Exception:       # noqa: BLE001
         co = None
     rnd = random.Random(1)
-    print("%-8s %8s %12s %14s %12s %14s" % ("group", "n", "msm ms", "resident ms", "cpu msm ms", "scalar_pair ms"))
+    cores = os.cpu_count() or 1
+    cpu_threads = min(32, cores)               # the reference's convention: 32 threads per task (run_single_bench:5-7)
+    if co is not None:
+        co.set_threads(cpu_threads)
+    print("# CPU columns: oracle/c restatement on %d of this box's %d host threads" % (cpu_threads, cores))
+    # ---- pairings: hk_multi_pairing (one product) and hk_pairing_products (the 4 x 4 cross terms, aggregation.rs:255-263)
+    print("%-8s %8s %14s %16s %14s %18s" % ("pairing", "n", "1 product ms", "16 products ms", "cpu 1 prod ms", "cpu 16 prods ms"))
+    gen1, gen2 = fc.g1(p["g1"]), fc.g2(p["g2"])
+    for n in (64, 256, 1024, 4096):
+        v1 = [ctx.fixed_base(1, gen1, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])) for _ in range(4)]
+        v2 = [ctx.fixed_base(2, gen2, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])) for _ in range(4)]
+        d1 = [capi.DeviceBuffer.from_host(ctx, v) for v in v1]
+        d2 = [capi.DeviceBuffer.from_host(ctx, v) for v in v2]
+        ctx.multi_pairing(d1[0], d2[0], n=n)
+        reps = 5
+        t0 = time.time()
+        for _ in range(reps):
+            one = ctx.multi_pairing(d1[0], d2[0], n=n)
+        t_one = (time.time() - t0) / reps
+        ctx.pairing_products(d1, d2, n=n)
+        t0 = time.time()
+        for _ in range(reps):
+            allp = ctx.pairing_products(d1, d2, n=n)
+        t_all = (time.time() - t0) / reps
+        assert np.array_equal(allp[0, 0], one)
+        t_c1 = t_c16 = float("nan")
+        if co is not None:
+            t0 = time.time()
+            ref = co.multi_pairing(v1[0], v2[0], n=n)
+            t_c1 = time.time() - t0
+            assert np.array_equal(ref, one), "GPU pairing differs from the CPU restatement"
+            if n <= 1024:
+                t0 = time.time()
+                for a in v1:
+                    for b in v2:
+                        co.multi_pairing(a, b, n=n)
+                t_c16 = time.time() - t0
+        print("%-8s %8d %14.3f %16.3f %14.3f %18.3f" % (curve, n, t_one * 1e3, t_all * 1e3, t_c1 * 1e3, t_c16 * 1e3))
+        for b in d1 + d2:
+            b.free()
+    print("%-8s %8s %12s %14s %12s %14s %18s" % ("group", "n", "msm ms", "resident ms", "cpu msm ms", "scalar_pair ms", "cpu scalar_pair ms"))
     for group in (1, 2):
         gen = fc.g1(p["g1"]) if group == 1 else fc.g2(p["g2"])
         pb = ctx.g1_bytes if group == 1 else ctx.g2_bytes
@@ -59,13 +99,16 @@ def main():
             for _ in range(reps):
                 ctx.scalar_pairing(group, bases, scal, n=n)
             t_sp = (time.time() - t0) / reps
-            t_cpu = float("nan")
+            t_cpu = t_csp = float("nan")
             if co is not None and n <= 8192:
                 bh = bases.to_host()
                 t0 = time.time()
                 co.msm(group, bh, scal_h)
                 t_cpu = time.time() - t0
-            print("%-8s %8d %12.3f %14.3f %12.3f %14.3f" % ("G%d" % group, n, t_msm * 1e3, t_res * 1e3, t_cpu * 1e3, t_sp * 1e3))
+                t0 = time.time()
+                co.scalar_mul_each(group, bh, scal_h)
+                t_csp = time.time() - t0
+            print("%-8s %8d %12.3f %14.3f %12.3f %14.3f %18.3f" % ("G%d" % group, n, t_msm * 1e3, t_res * 1e3, t_cpu * 1e3, t_sp * 1e3, t_csp * 1e3))
             bases.free()
             scal.free()
 
