@@ -837,13 +837,13 @@ hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n
     Lane* L = g.lane;
     if (!L) return HK_ERR_DEVICE;
     size_t g1b = sizeof(Affine<Fq>), g2b = sizeof(Affine<Fq2>);
-    size_t need = al256(n_lhs * n * g1b) + al256(n_rhs * n * g2b) + al256(n * count * sizeof(GT)) +
+    size_t need = al256(n_lhs * n * g1b) + al256(n_rhs * n * g2b) + al256(2 * n * count * sizeof(GT)) +
                   2 * al256(count * sizeof(GT)) + 8192;
     HK_TRY(L->reserve(need));
     hipStream_t s = L->stream;
     Affine<Fq>* d1 = L->alloc_n<Affine<Fq>>(n_lhs * n);
     Affine<Fq2>* d2 = L->alloc_n<Affine<Fq2>>(n_rhs * n);
-    GT* miller = L->alloc_n<GT>(n * count);
+    GT* miller = L->alloc_n<GT>(2 * n * count);          // Miller values + the ping-pong half of the product tree
     GT* prod = L->alloc_n<GT>(count);
     GT* res = L->alloc_n<GT>(count);
     if (!d1 || !d2 || !miller || !prod || !res) return HK_ERR_NOMEM;
