@@ -1,0 +1,160 @@
+"""Host-side mirror of the aggregator's front half over the C ABI.
+
+    IPCommKey / TIPPCommitment.{commit_only_left, commit_only_right, commit_with_ip}, IppCom (+, * scalar)
+                                    ark-ip-proofs `ip_commitment::snarkpack::TIPPCommitment` as the reference uses it:
+                                    distributed-prover/src/aggregation.rs:18,97-103,167-168; coordinator.rs:339
+    tipa_commitment_key             the commitment-key part of `TIPA::setup` (mpi-snark/src/coordinator.rs:80-97)
+    AggProvingKey.new               distributed-prover/src/aggregation.rs:60-135
+    AggProvingKey.agg_front         distributed-prover/src/aggregation.rs:138-330: everything `agg_subcircuit_proofs` does
+                                    BEFORE `TIPA::prove` - commitments, prepared inputs, twisted vectors, the 4 x 4 cross
+                                    terms, the s/t combination, com_lr, z_lr - i.e. the TIPA instance and witness
+
+All group arithmetic runs on the GPU: multi-pairings (hk_pairing_products), element-wise scalar multiplications
+(hk_scalar_pairing), element-wise linear combinations (hk_points_lincomb).  GT products / powers of commitments
+(three per job) are host arithmetic (gt.py).  NOT mirrored: the Fiat-Shamir transcript (merlin, third-party) - the
+challenges r (twist), s, t are arguments - and `TIPA::prove / verify` themselves (the GIPA recursion of the third-party
+`ripp` crate, absent from /root/reference; its building blocks are exactly the primitives above plus hk_msm_bases for the
+KZG openings).  PARITY UNPINNED for the snarkpack commitment layout (T = e(A, v1) e(w1, B), U = e(A, v2) e(w2, B),
+restated from the SnarkPack paper); what the tests pin is the reference's own debug assertions
+(aggregation.rs:208-216,246-253,265-269) holding on proofs made by this prover.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .cp_groth16 import CURVE_PARAMS, FrCodec
+from .gt import GtField
+
+
+@dataclass
+class IPCommKey:
+    """SnarkPack pair commitment key: v1, v2 in G2^n (commit the left / G1 vector), w1, w2 in G1^n (right / G2 vector)."""
+    v1: np.ndarray
+    v2: np.ndarray
+    w1: np.ndarray
+    w2: np.ndarray
+    n: int
+
+
+def tipa_commitment_key(ctx, curve, n, a, b):
+    """v1 = h^(a^i), v2 = h^(b^i), w1 = g^(a^(n+i)), w2 = g^(b^(n+i)), i < n (the structured key `TIPA::setup` derives from
+    its two trapdoors), built with the GPU fixed-base path."""
+    p = CURVE_PARAMS[curve]
+    fc = FrCodec(curve)
+    r = p["r"]
+    pa, pb = [1] * (2 * n), [1] * (2 * n)
+    for i in range(1, 2 * n):
+        pa[i] = pa[i - 1] * a % r
+        pb[i] = pb[i - 1] * b % r
+    G1, G2 = fc.g1(p["g1"]), fc.g2(p["g2"])
+    return IPCommKey(v1=np.asarray(ctx.fixed_base(2, G2, fc.enc(pa[:n]))), v2=np.asarray(ctx.fixed_base(2, G2, fc.enc(pb[:n]))),
+                     w1=np.asarray(ctx.fixed_base(1, G1, fc.enc(pa[n:]))), w2=np.asarray(ctx.fixed_base(1, G1, fc.enc(pb[n:]))), n=n)
+
+
+class IppCom:
+    """`Commitment<TIPPCommitment<E>>`: (T, U) in GT x GT and, for commit_with_ip, the inner product.  `+` multiplies
+    in GT, `* k` raises to k (the reference's additive notation)."""
+
+    def __init__(self, F, t, u, ip=None):
+        self.F, self.t, self.u, self.ip = F, t, u, ip
+
+    def __add__(self, o):
+        ip = None if (self.ip is None and o.ip is None) else self.F.mul(self.ip or self.F.one, o.ip or self.F.one)
+        return IppCom(self.F, self.F.mul(self.t, o.t), self.F.mul(self.u, o.u), ip)
+
+    def __mul__(self, k):
+        ip = None if self.ip is None else self.F.pow(self.ip, k)
+        return IppCom(self.F, self.F.pow(self.t, k), self.F.pow(self.u, k), ip)
+
+    def __eq__(self, o):
+        return self.t == o.t and self.u == o.u and (self.ip or self.F.one) == (o.ip or self.F.one)
+
+    def to_bytes(self):
+        return self.F.encode(self.t) + self.F.encode(self.u) + (self.F.encode(self.ip) if self.ip is not None else b"")
+
+
+class TIPPCommitment:
+    def __init__(self, ctx, curve):
+        self.ctx, self.F = ctx, GtField(curve)
+
+    def commit_only_left(self, ck, left):
+        """(e(A, v1), e(A, v2)) - aggregation.rs:97-100,168; coordinator.rs:339 (the super-commitment to all stage-0
+        commitments, on the coordinator's critical path between the two rounds)."""
+        out = self.ctx.pairing_products([left], [ck.v1, ck.v2], n=ck.n)
+        return IppCom(self.F, self.F.decode(out[0, 0]), self.F.decode(out[0, 1]))
+
+    def commit_only_right(self, ck, right):
+        """(e(w1, B), e(w2, B)) - aggregation.rs:101-103."""
+        out = self.ctx.pairing_products([ck.w1, ck.w2], [right], n=ck.n)
+        return IppCom(self.F, self.F.decode(out[0, 0]), self.F.decode(out[1, 0]))
+
+    def commit_with_ip(self, ck, left, right):
+        """T = e(A, v1) e(w1, B), U = e(A, v2) e(w2, B), Z = e(A, B) - aggregation.rs:167."""
+        l = self.ctx.pairing_products([left], [ck.v1, ck.v2, right], n=ck.n)
+        r = self.ctx.pairing_products([ck.w1, ck.w2], [right], n=ck.n)
+        F = self.F
+        return IppCom(F, F.mul(F.decode(l[0, 0]), F.decode(r[0, 0])), F.mul(F.decode(l[0, 1]), F.decode(r[1, 0])),
+                      F.decode(l[0, 2]))
+
+
+class AggProvingKey:
+    """distributed-prover/src/aggregation.rs:23-135.  `vks[i]`: the Groth16 verifying-key parts of subcircuit i's class
+    (cp_groth16.VerifyingKey): gamma_abc_g (4 G1), gamma_h, deltas_h (2 G2), alpha_g, beta_h."""
+
+    def __init__(self, ctx, curve, ck, vks):
+        self.ctx, self.curve, self.ck = ctx, curve, ck
+        self.com = TIPPCommitment(ctx, curve)
+        self.F = self.com.F
+        g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
+        cat = lambda xs: np.concatenate([np.asarray(x, np.uint8) for x in xs])
+        self.n = len(vks)
+        assert self.n == ck.n
+        self.s = [cat([vk.gamma_abc_g[j * g1b:(j + 1) * g1b] for vk in vks]) for j in range(4)]      # :84-87
+        self.h = cat([vk.gamma_h for vk in vks])                                                    # :88
+        self.delta0 = cat([vk.deltas_h[:g2b] for vk in vks])                                        # :89
+        self.delta1 = cat([vk.deltas_h[g2b:2 * g2b] for vk in vks])                                 # :90
+        self.alpha = cat([vk.alpha_g for vk in vks])                                                # :91
+        self.beta = cat([vk.beta_h for vk in vks])                                                  # :92
+        self.com_s = [self.com.commit_only_left(ck, v) for v in self.s]                             # :97-100
+        self.com_h = self.com.commit_only_right(ck, self.h)                                         # :101
+        self.com_delta0 = self.com.commit_only_right(ck, self.delta0)                               # :102
+        self.com_delta1 = self.com.commit_only_right(ck, self.delta1)                               # :103
+
+    def agg_front(self, super_com, proofs, pub_inputs, twist, s, t):
+        """aggregation.rs:138-330 up to the `TIPA::prove` call.  proofs: [cp_groth16.Proof] with one stage-0
+        commitment each; pub_inputs: 3 ints; twist, s, t: the Fiat-Shamir challenges (ints).  Returns a dict with the
+        TIPA instance (`output` = z_lr, `commitment` = com_lr, `twist`), the witness (`left`, `right`) and the 4 x 4
+        `cross_terms`; raises AssertionError if the pairing-product equation of :265-269 fails."""
+        ctx, F, ck, fc = self.ctx, self.F, self.ck, FrCodec(self.curve)
+        r_mod = CURVE_PARAMS[self.curve]["r"]
+        n = len(proofs)
+        assert n == self.n
+        cat = lambda xs: np.concatenate([np.asarray(x, np.uint8) for x in xs])
+        a_vals, b_vals = cat([p.a for p in proofs]), cat([p.b for p in proofs])
+        c_vals, d_vals = cat([p.c for p in proofs]), cat([p.ds[0] for p in proofs])
+        com_ab = self.com.commit_with_ip(ck, a_vals, b_vals)                                        # :167
+        com_c = self.com.commit_only_left(ck, c_vals)                                               # :168
+        com_d = super_com
+        x = [v % r_mod for v in pub_inputs]
+        com_prepared_input = self.com_s[0] + self.com_s[1] * x[0] + self.com_s[2] * x[1] + self.com_s[3] * x[2]   # :171-174
+        prepared_input = ctx.points_lincomb(1, self.s, fc.enc([1] + x), n=n)                        # :192-205
+        tw = [1] * n                                                                                # :224 structured_scalar_power
+        for i in range(1, n):
+            tw[i] = tw[i - 1] * twist % r_mod
+        twb = fc.enc(tw)
+        a_r, c_r, d_r, alpha_r, input_r = (ctx.scalar_pairing(1, v, twb, n=n)                       # :236-242
+                                           for v in (a_vals, c_vals, d_vals, self.alpha, prepared_input))
+        cross = ctx.pairing_products([a_r, input_r, d_r, c_r], [b_vals, self.h, self.delta0, self.delta1], n=n)   # :255-263
+        z = [[F.decode(cross[i, j]) for j in range(4)] for i in range(4)]
+        z_alpha_beta = F.decode(ctx.multi_pairing(alpha_r, self.beta, n=n))
+        rhs = F.mul(F.mul(z_alpha_beta, z[1][1]), F.mul(z[2][2], z[3][3]))
+        assert z[0][0] == rhs, "pairing-product equation of the twisted proofs does not hold (aggregation.rs:265-269)"
+        s2, s3, t2, t3 = s * s % r_mod, s * s * s % r_mod, t * t % r_mod, t * t * t % r_mod
+        left = ctx.points_lincomb(1, [a_vals, prepared_input, d_vals, c_vals], fc.enc([1, s, s2, s3]), n=n)       # :293-310
+        right = ctx.points_lincomb(2, [b_vals, self.h, self.delta0, self.delta1], fc.enc([1, t, t2, t3]), n=n)    # :311-326
+        com_lr = (com_ab + com_prepared_input * s + com_d * s2 + com_c * s3) + \
+                 (self.com_h * t + self.com_delta0 * t2 + self.com_delta1 * t3)                     # :328-332
+        left_r = ctx.scalar_pairing(1, left, twb, n=n)                                              # twisted_inner_product
+        z_lr = F.decode(ctx.multi_pairing(left_r, right, n=n))                                      # :334
+        return dict(size=n, output=z_lr, commitment=com_lr, twist=twist, left=left, right=right, cross_terms=z,
+                    com_ab=com_ab, com_c=com_c, prepared_input=prepared_input)

@@ -59,7 +59,8 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_ctx_set_profiling", "hk_ctx_last_timings", "hk_ctx_sizes", "hk_dev_alloc", "hk_dev_free",
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
-           "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes"]
+           "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2"]
 
 _lib = None
 
@@ -103,6 +104,8 @@ def load():
     lib.hk_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
     lib.hk_pairing_products.argtypes = [vp, C.POINTER(vp), sz, C.POINTER(vp), sz, sz, vp]
     lib.hk_ctx_gt_bytes.argtypes = [vp, C.POINTER(sz)]
+    for f in (lib.hk_points_lincomb_g1, lib.hk_points_lincomb_g2):
+        f.argtypes = [vp, C.POINTER(vp), vp, sz, sz, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -263,6 +266,18 @@ class Context:
         out = np.zeros((len(lhs), len(rhs), self.gt_bytes), dtype=np.uint8)
         check(self.lib.hk_pairing_products(self.handle, lp, len(lhs), rp, len(rhs), n, out.ctypes.data),
               "hk_pairing_products")
+        return out
+
+    def points_lincomb(self, group, vecs, coeffs, n=None):
+        """out[i] = sum_j coeffs[j] * vecs[j][i] (aggregation.rs:192-203,293-326); coeffs: k Fr Montgomery bytes."""
+        pb = self.g1_bytes if group == 1 else self.g2_bytes
+        n = n if n is not None else len(vecs[0]) // pb
+        keep = [x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8) for x in vecs]
+        vp_ = (C.c_void_p * len(keep))(*[x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data for x in keep])
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint8)
+        out = np.zeros(n * pb, dtype=np.uint8)
+        fn = self.lib.hk_points_lincomb_g1 if group == 1 else self.lib.hk_points_lincomb_g2
+        check(fn(self.handle, vp_, coeffs.ctypes.data, len(keep), n, out.ctypes.data), fn.__name__)
         return out
 
     def bases_upload(self, group, bases, n=None):

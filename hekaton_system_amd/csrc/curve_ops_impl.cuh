@@ -111,13 +111,14 @@ struct Ops {
     static void bases_free(hk_bases*);
     static hk_status msm_bases(hk_ctx*, const hk_bases*, const void*, size_t, int, int, void*);
     static hk_status pairing_products(hk_ctx*, const void* const*, size_t, const void* const*, size_t, size_t, void*);
+    static hk_status points_lincomb(hk_ctx*, int, const void* const*, const void*, size_t, size_t, void*);
 
     static const CurveOps* table() {
         static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
-                                   sizeof(Fp12<typename Fq::Params>)};
+                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb};
         return &t;
     }
 };

@@ -56,6 +56,33 @@ k_fb_mul(const Affine<F>* __restrict__ table, const Fr* __restrict__ scalars, in
     st_vec(&out[i], acc);
 }
 
+// out[i] = sum_j coeffs[j] * vecs[j][i]  (XYZZ), one lane per element, ONE shared doubling chain for the k <= 8 terms
+// (Straus): the aggregator's element-wise combinations - `prepared_input = s0 + s1*x0 + s2*x1 + s3*x2`
+// (distributed-prover/src/aggregation.rs:192-203) and `left = A + S^s + D^(s^2) + C^(s^3)`, `right = B + H^t + ...`
+// (:293-326: three scalar_pairing sweeps with a constant scalar followed by element-wise additions).
+constexpr int LINCOMB_MAX = 8;
+template <class F> struct LincombVecs { const Affine<F>* v[LINCOMB_MAX]; };
+template <class Fr, class F>
+__global__ void __launch_bounds__(64)
+k_points_lincomb(LincombVecs<F> vecs, const Fr* __restrict__ coeffs_mont, u32 k, u32 n, XYZZ<F>* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr c[LINCOMB_MAX];
+    int top = -1;
+    for (u32 j = 0; j < k; j++) {
+        c[j] = Fr::from_mont(ld_vec(&coeffs_mont[j]));
+        for (int b = Fr::N * 32 - 1; b > top; b--)
+            if ((c[j].v[b >> 5] >> (b & 31)) & 1) { top = b; break; }
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    HK_NOUNROLL for (int b = top; b >= 0; b--) {
+        acc = ec_dbl_ni(acc);
+        HK_NOUNROLL for (u32 j = 0; j < k; j++)
+            if ((c[j].v[b >> 5] >> (b & 31)) & 1) acc = ec_madd_ni(acc, ld_vec(&vecs.v[j][i]));
+    }
+    st_vec(&out[i], acc);
+}
+
 // out[i] = scalars[i] * points[i] (XYZZ), one lane per element, plain double-and-add over the canonical scalar
 // (`scalar_pairing`, distributed-prover/src/pairing_ops.rs:32-39; N = #subcircuits <= 1024, latency-bound)
 template <class Fr, class F>

@@ -247,6 +247,14 @@ hk_status hk_msm_bases(hk_ctx* ctx, const hk_bases* b, const void* scalars, size
     if (!ctx || !b || !out || b->ctx != ctx) return HK_ERR_ARG;
     return ctx->ops->msm_bases(ctx, b, scalars, n_scalars, mont, checked, out);
 }
+hk_status hk_points_lincomb_g1(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out) {
+    if (!ctx || !vecs || !coeffs_mont || (n && !out)) return HK_ERR_ARG;
+    return ctx->ops->points_lincomb(ctx, 1, vecs, coeffs_mont, k, n, out);
+}
+hk_status hk_points_lincomb_g2(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out) {
+    if (!ctx || !vecs || !coeffs_mont || (n && !out)) return HK_ERR_ARG;
+    return ctx->ops->points_lincomb(ctx, 2, vecs, coeffs_mont, k, n, out);
+}
 hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2,
                               size_t n_rhs, size_t n, void* gt_out) {
     if (!ctx || !lhs_g1 || !rhs_g2 || !gt_out) return HK_ERR_ARG;

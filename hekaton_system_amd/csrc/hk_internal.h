@@ -112,6 +112,8 @@ struct CurveOps {
     hk_status (*pairing_products)(hk_ctx*, const void* const* lhs, size_t n_lhs, const void* const* rhs, size_t n_rhs,
                                   size_t n, void* out);
     size_t gt_bytes;
+    hk_status (*points_lincomb)(hk_ctx*, int group, const void* const* vecs, const void* coeffs, size_t k, size_t n,
+                                void* out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

@@ -49,6 +49,9 @@ struct MsmRun {
     // out[i] = scalars[i] * points[i] (pairing_ops.rs:32-39); xy / pref: n-element scratch
     static hk_status scalar_mul_each(hipStream_t s, const Affine<F>* pts, const void* scalars_mont, u32 n,
                                      XYZZ<F>* xy, F* pref, Affine<F>* out);
+    // out[i] = sum_j coeffs[j] * vecs[j][i], k <= LINCOMB_MAX (aggregation.rs:192-203,293-326)
+    static hk_status lincomb(hipStream_t s, const Affine<F>* const* vecs, const void* coeffs_mont, u32 k, u32 n,
+                             XYZZ<F>* xy, F* pref, Affine<F>* out);
 };
 
 // multi-pairing launch sequence (pairing.cuh); explicit instantiation in hk_<curve>_pair.hip

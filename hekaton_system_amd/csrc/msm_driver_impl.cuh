@@ -159,6 +159,19 @@ hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const 
 }
 
 template <class F>
+hk_status MsmRun<F>::lincomb(hipStream_t s, const Affine<F>* const* vecs, const void* coeffs_mont, u32 k, u32 n,
+                             XYZZ<F>* xy, F* pref, Affine<F>* out) {
+    typedef typename ScalarOf<F>::type Fr;
+    if (n == 0) return HK_OK;
+    if (k == 0 || k > (u32)LINCOMB_MAX) return HK_ERR_ARG;
+    LincombVecs<F> lv;
+    for (u32 j = 0; j < (u32)LINCOMB_MAX; j++) lv.v[j] = j < k ? vecs[j] : nullptr;
+    hipLaunchKernelGGL((k_points_lincomb<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, lv, (const Fr*)coeffs_mont, k, n, xy);
+    HK_HIP(hipGetLastError());
+    return batch_affine(s, xy, out, pref, n);
+}
+
+template <class F>
 hk_status MsmRun<F>::fixed_base(hipStream_t s, const Affine<F>* base, const void* scalars, int is_mont,
                                 u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out) {
     typedef typename ScalarOf<F>::type Fr;

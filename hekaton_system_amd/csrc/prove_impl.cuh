@@ -817,6 +817,41 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
     return group == 1 ? run(Fq()) : run(Fq2());
 }
 
+template <class C>
+hk_status Ops<C>::points_lincomb(hk_ctx* ctx, int group, const void* const* vecs, const void* coeffs, size_t k,
+                                 size_t n, void* out) {
+    if (n == 0) return HK_OK;
+    if (k == 0 || k > (size_t)LINCOMB_MAX || n >= (1u << 28)) return HK_ERR_ARG;
+    for (size_t j = 0; j < k; j++) if (!vecs[j]) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    auto run = [&](auto ftag) -> hk_status {
+        typedef decltype(ftag) F;
+        size_t need = (k + 1) * al256(n * sizeof(Affine<F>)) + al256(k * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
+                      al256(n * sizeof(F)) + 8192;
+        HK_TRY(L->reserve(need));
+        const Affine<F>* dv[LINCOMB_MAX];
+        for (size_t j = 0; j < k; j++) {
+            const void* d;
+            HK_TRY(to_device(L, vecs[j], n * sizeof(Affine<F>), &d));
+            dv[j] = (const Affine<F>*)d;
+        }
+        const void* cd;
+        HK_TRY(to_device(L, coeffs, k * sizeof(Fr), &cd));
+        XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
+        F* pref = L->alloc_n<F>(n);
+        bool out_dev = is_device_ptr(out);
+        Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
+        if (!xy || !pref || !od) return HK_ERR_NOMEM;
+        HK_TRY(MsmRun<F>::lincomb(L->stream, dv, cd, (u32)k, (u32)n, xy, pref, od));
+        if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+        HK_HIP(hipStreamSynchronize(L->stream));
+        return HK_OK;
+    };
+    return group == 1 ? run(Fq()) : run(Fq2());
+}
+
 // ---- multi-pairings (pairing.cuh) ------------------------------------------------------------------------------
 template <class C>
 hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n_lhs, const void* const* rhs,

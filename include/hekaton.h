@@ -177,6 +177,14 @@ hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_l
                               size_t n_rhs, size_t n, void* gt_out);
 hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt);
 
+/* Element-wise linear combination of k <= 8 point vectors: out[i] = sum_j coeffs[j] * vecs[j][i], batch-normalised to
+ * affine.  Replaces the aggregator's `prepared_input = s0 + s1*x0 + s2*x1 + s3*x2` (distributed-prover/src/
+ * aggregation.rs:192-203) and the `left` / `right` combinations of :293-326 (three constant-scalar `scalar_pairing`
+ * sweeps + element-wise additions each) with ONE launch sharing one doubling chain.
+ * vecs [h]: k pointers, each [h|d] to n packed affine points; coeffs_mont [h|d]: k Fr; out [h|d]: n packed affine. */
+hk_status hk_points_lincomb_g1(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out);
+hk_status hk_points_lincomb_g2(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out);
+
 /* ---- MSM over a RESIDENT base set ----------------------------------------------------------------------
  * Bases that are key material (the KZG / commitment-key powers of the aggregator's SRS, any static query) are
  * uploaded once together with their 2^(16 g) multiples, exactly like the proving-key queries; every later MSM over
