@@ -101,11 +101,12 @@ def load():
     lib.hk_bases_free.argtypes = [vp]
     lib.hk_bases_free.restype = None
     lib.hk_msm_bases.argtypes = [vp, vp, vp, sz, i, i, vp]
-    lib.hk_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
-    lib.hk_pairing_products.argtypes = [vp, C.POINTER(vp), sz, C.POINTER(vp), sz, sz, vp]
-    lib.hk_ctx_gt_bytes.argtypes = [vp, C.POINTER(sz)]
-    for f in (lib.hk_points_lincomb_g1, lib.hk_points_lincomb_g2):
-        f.argtypes = [vp, C.POINTER(vp), vp, sz, sz, vp]
+    if hasattr(lib, "hk_multi_pairing"):          # absent only from older experiment builds loaded through HK_LIB
+        lib.hk_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
+        lib.hk_pairing_products.argtypes = [vp, C.POINTER(vp), sz, C.POINTER(vp), sz, sz, vp]
+        lib.hk_ctx_gt_bytes.argtypes = [vp, C.POINTER(sz)]
+        for f in (lib.hk_points_lincomb_g1, lib.hk_points_lincomb_g2):
+            f.argtypes = [vp, C.POINTER(vp), vp, sz, sz, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -181,8 +182,9 @@ class Context:
         fr, fq, g1, g2 = (C.c_size_t() for _ in range(4))
         check(self.lib.hk_ctx_sizes(h, C.byref(fr), C.byref(fq), C.byref(g1), C.byref(g2)), "hk_ctx_sizes")
         self.fr_bytes, self.fq_bytes, self.g1_bytes, self.g2_bytes = fr.value, fq.value, g1.value, g2.value
-        gt = C.c_size_t()
-        check(self.lib.hk_ctx_gt_bytes(h, C.byref(gt)), "hk_ctx_gt_bytes")
+        gt = C.c_size_t(12 * fq.value)
+        if hasattr(self.lib, "hk_ctx_gt_bytes"):
+            check(self.lib.hk_ctx_gt_bytes(h, C.byref(gt)), "hk_ctx_gt_bytes")
         self.gt_bytes = gt.value
 
     def close(self):

@@ -349,7 +349,7 @@ __device__ __forceinline__ void msm_accum_level(int level, u32 t, const LevelInf
             key = kk;
         }
         XYZZ<F> q = ld_vec(&pts_in[pos]);
-        if (!q.is_inf()) acc = ec_add_ni(acc, q);
+        if (!q.is_inf()) acc = ec_add(acc, q);
     }
     bool tail_partial = end < li.count && keys_in[end] == key;
     XYZZ<F> tail = XYZZ<F>::inf();

@@ -57,10 +57,11 @@ struct MsmRun {
 // multi-pairing launch sequence (pairing.cuh); explicit instantiation in hk_<curve>_pair.hip
 template <class P>
 struct PairRun {
-    // g1: n_l vectors of n points, g2: n_r vectors of n points (device).  miller: 2*n*n_l*n_r Fq12 scratch,
+    // g1: n_l vectors of n points, g2: n_r vectors of n points (device).  miller: scratch_bytes(n, n_l*n_r) of scratch,
     // prod: n_l*n_r scratch, out: n_l*n_r results (device), out[a*n_r + b] = prod_i e(g1[a][i], g2[b][i]).
     static hk_status run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<Fp2<P>>* g2, u32 n, u32 n_l, u32 n_r,
                          Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out);
+    static size_t scratch_bytes(u32 n, u32 count);        // size of `miller` (lines + tree buffers, or Miller values)
 };
 
 }  // namespace hk

@@ -10,16 +10,28 @@ template <> struct PairLoopOf<Bn254FqP> { static PairLoop get() { return pair_lo
 template <> struct PairLoopOf<Bls381FqP> { static PairLoop get() { return pair_loop_bls381(); } };
 
 template <class P>
+size_t PairRun<P>::scratch_bytes(u32 n, u32 count) {
+    PairSteps st = pair_steps(PairLoopOf<P>::get(), TowerParams<P>::TWIST_IS_D);
+    size_t S = (size_t)st.n, g0 = (n + 15) / 16;
+    size_t lines = ((size_t)count * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;
+    size_t pipeline = lines + 2 * count * S * g0 * sizeof(Fp12<P>);
+    size_t serial = (size_t)n * count * sizeof(Fp12<P>);
+    return (pipeline > serial ? pipeline : serial) + 4096;
+}
+
+template <class P>
 hk_status PairRun<P>::run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<Fp2<P>>* g2, u32 n, u32 n_l, u32 n_r,
                           Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out) {
     u32 count = n_l * n_r;
     size_t total = (size_t)n * count;
     if (count == 0 || n == 0) return HK_ERR_ARG;
     PairLoop loop = PairLoopOf<P>::get();
-    hipLaunchKernelGGL((k_pair_miller<P>), dim3((u32)((total + 63) / 64)), dim3(64), 0, s, g1, g2, n, n_l, n_r, loop, miller);
-    HK_DBG(s, "k_pair_miller");
-    static const bool serial = getenv("HK_PAIR_SERIAL") != nullptr;      // the one-lane-per-product tail (A/B, debugging)
+    static const bool serial = getenv("HK_PAIR_SERIAL") != nullptr;      // one lane per pair / per product (A/B, debugging)
+    size_t lds_tree = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
+    size_t lds_fin = sizeof(WaveArea<P>) + WV_FINISH_SLOTS * WV_SLOT * sizeof(Fp<P>);
     if (serial) {
+        hipLaunchKernelGGL((k_pair_miller<P>), dim3((u32)((total + 63) / 64)), dim3(64), 0, s, g1, g2, n, n_l, n_r, loop, miller);
+        HK_DBG(s, "k_pair_miller");
         hipLaunchKernelGGL((k_f12_product<P>), dim3(count), dim3(PAIR_TREE_THREADS), sizeof(Fp12<P>) * PAIR_TREE_THREADS, s,
                            (const Fp12<P>*)miller, n, prod);
         HK_DBG(s, "k_f12_product");
@@ -27,23 +39,33 @@ hk_status PairRun<P>::run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<F
                            (const Fp12<P>*)prod, count, out);
         HK_DBG(s, "k_final_exp");
     } else {
-        // wave-parallel tail: tree levels of 16 (one wave per group), then one wave per product finishes the product
-        // and runs the final exponentiation.  The two halves of `miller` (sized 2 x n x count) are the ping-pong
-        // buffers of the tree.
-        size_t lds_tree = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
-        size_t lds_fin = sizeof(WaveArea<P>) + WV_FINISH_SLOTS * WV_SLOT * sizeof(Fp<P>);
-        const Fp12<P>* cur = miller;
-        u32 m = n;
-        while (m > 32) {
+        // pipeline (pairing_wave.cuh): lines -> per-step product trees (wave multiplier) -> Horner + final exponentiation
+        PairSteps st = pair_steps(loop, TowerParams<P>::TWIST_IS_D);
+        u32 S = (u32)st.n;
+        Line6<P>* lines = reinterpret_cast<Line6<P>*>(miller);
+        // buffers behind the lines: two ping-pong arrays of at most count * S * ceil(n / 16) Fq12
+        size_t lines_bytes = ((size_t)count * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;
+        u32 g0 = (n + 15) / 16;
+        Fp12<P>* pp[2];
+        pp[0] = reinterpret_cast<Fp12<P>*>(reinterpret_cast<char*>(miller) + lines_bytes);
+        pp[1] = pp[0] + (size_t)count * S * g0;
+        hipLaunchKernelGGL((k_pair_lines<P>), dim3((u32)(((size_t)n * n_r + 63) / 64)), dim3(64), 0, s, g1, g2, n, n_l, n_r,
+                           loop, S, lines);
+        HK_DBG(s, "k_pair_lines");
+        hipLaunchKernelGGL((k_pair_tree_lines<P>), dim3(g0, count * S), dim3(64), lds_tree, s, (const Line6<P>*)lines, n, 16u, pp[0]);
+        HK_DBG(s, "k_pair_tree_lines");
+        u32 m = g0;
+        int cur = 0;
+        while (m > 1) {
             u32 groups = (m + 15) / 16;
-            Fp12<P>* dst = miller + (cur == miller ? (size_t)n * count : 0);
-            hipLaunchKernelGGL((k_pair_tree<P>), dim3(groups, count), dim3(64), lds_tree, s, cur, m, 16u, dst);
+            hipLaunchKernelGGL((k_pair_tree<P>), dim3(groups, count * S), dim3(64), lds_tree, s, (const Fp12<P>*)pp[cur], m, 16u,
+                               pp[cur ^ 1]);
             HK_DBG(s, "k_pair_tree");
-            cur = dst;
+            cur ^= 1;
             m = groups;
         }
-        hipLaunchKernelGGL((k_pair_finish<P>), dim3(count), dim3(64), lds_fin, s, cur, m, out);
-        HK_DBG(s, "k_pair_finish");
+        hipLaunchKernelGGL((k_pair_horner<P>), dim3(count), dim3(64), lds_fin, s, (const Fp12<P>*)pp[cur], st, out);
+        HK_DBG(s, "k_pair_horner");
     }
     HK_HIP(hipGetLastError());
     return HK_OK;

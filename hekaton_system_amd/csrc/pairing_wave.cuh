@@ -245,6 +245,137 @@ struct WaveF12 {
 
 constexpr int WV_FINISH_SLOTS = 12;
 
+// ---- the Miller loop as a pipeline -------------------------------------------------------------------------------
+// prod_i f_i with f_i = Miller(P_i, Q_i) is regrouped by loop step: f = prod_s L_s^(2^(squarings after s)),
+// L_s = prod_i line_{i,s}(P_i).  (1) k_pair_lines: one lane per G2 point walks ark's projective steps ONCE and writes
+// every line, evaluated at each lhs vector's G1 point (the step arithmetic is shared by all lhs vectors);
+// (2) k_pair_tree_lines / k_pair_tree: L_s by product trees on the wave multiplier, all steps and products in parallel;
+// (3) k_pair_horner: one wave per product folds the L_s with the loop's squarings and runs the final exponentiation.
+struct PairSteps {
+    int n;                       // number of line steps S
+    unsigned char sq[100];       // sq[s] != 0: the accumulator is squared before line s is multiplied in
+};
+inline PairSteps pair_steps(const PairLoop& loop, bool is_bn) {
+    PairSteps st;
+    st.n = 0;
+    for (int i = loop.len - 1; i >= 1; i--) {
+        st.sq[st.n++] = i != loop.len - 1;
+        if (loop.digits[i - 1] != 0) st.sq[st.n++] = 0;
+    }
+    if (is_bn) { st.sq[st.n++] = 0; st.sq[st.n++] = 0; }
+    return st;
+}
+
+template <class P> struct Line6 { Fp2<P> c0, c1, c2; };
+
+// lines[((a * n_r + b) * S + s) * n + i]
+template <class P>
+__global__ void __launch_bounds__(64)
+k_pair_lines(const Affine<Fp<P>>* __restrict__ g1, const Affine<Fp2<P>>* __restrict__ g2, u32 n, u32 n_l, u32 n_r,
+             PairLoop loop, u32 S, Line6<P>* __restrict__ lines) {
+    typedef TowerParams<P> T;
+    typedef Fp2<P> F;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * n_r) return;
+    u32 i = (u32)(t % n), b = (u32)(t / n);
+    Affine<F> q = ld_vec(&g2[(size_t)b * n + i]);
+    bool q_inf = q.is_inf();
+    G2Proj<P> r;
+    r.x = q.x; r.y = q.y; r.z = F::one();
+    Affine<F> nq = q;
+    nq.y = F::neg(q.y);
+    Affine<F> q1 = q, q2 = q;
+    if (T::TWIST_IS_D && !q_inf) {
+        q1 = pair_mul_by_char(q);
+        q2 = pair_mul_by_char(q1);
+        q2.y = F::neg(q2.y);
+    }
+    u32 s = 0;
+    auto emit = [&](const LineCoeffs<P>& l) {
+        HK_NOUNROLL for (u32 a = 0; a < n_l; a++) {
+            Affine<Fp<P>> p = ld_vec(&g1[(size_t)a * n + i]);
+            Line6<P> o;
+            if (q_inf || p.is_inf()) { o.c0 = F::one(); o.c1 = F::zero(); o.c2 = F::zero(); }
+            else if (T::TWIST_IS_D) { o.c0 = f2_scale(l.c0, p.y); o.c1 = f2_scale(l.c1, p.x); o.c2 = l.c2; }
+            else { o.c0 = l.c0; o.c1 = f2_scale(l.c1, p.x); o.c2 = f2_scale(l.c2, p.y); }
+            Line6<P>* dst = &lines[(((size_t)a * n_r + b) * S + s) * n + i];
+            st_vec(&dst->c0, o.c0); st_vec(&dst->c1, o.c1); st_vec(&dst->c2, o.c2);
+        }
+        s++;
+    };
+    LineCoeffs<P> dummy; dummy.c0 = F::one(); dummy.c1 = F::zero(); dummy.c2 = F::zero();
+    HK_NOUNROLL for (int k = loop.len - 1; k >= 1; k--) {
+        emit(q_inf ? dummy : pair_doubling_step(r));
+        int d = loop.digits[k - 1];
+        if (d == 1) emit(q_inf ? dummy : pair_addition_step(r, q));
+        else if (d == -1) emit(q_inf ? dummy : pair_addition_step(r, nq));
+    }
+    if (T::TWIST_IS_D) {
+        emit(q_inf ? dummy : pair_addition_step(r, q1));
+        emit(q_inf ? dummy : pair_addition_step(r, q2));
+    }
+}
+
+// first tree level over SPARSE lines: wave g of group y multiplies lines[y][g*c .. ) into one full Fq12
+template <class P>
+__global__ void __launch_bounds__(64)
+k_pair_tree_lines(const Line6<P>* __restrict__ lines, u32 n, u32 c, Fp12<P>* __restrict__ out) {
+    extern __shared__ unsigned char pair_lds[];
+    typedef WaveF12<P> W;
+    typedef Fp<P> Fq;
+    typedef TowerParams<P> T;
+    WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
+    Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    Fq *acc = s, *cur = s + WV_SLOT;
+    u32 lo = blockIdx.x * c, hi = min(lo + c, n);
+    const Line6<P>* src = lines + (size_t)blockIdx.y * n;
+    u32 lane = threadIdx.x;
+    // sparse positions (ark mul_by_034 / mul_by_014): D: c0 -> 0,1  c1 -> 6,7  c2 -> 8,9;  M: c0 -> 0,1  c1 -> 2,3  c2 -> 8,9
+    auto load_line = [&](Fq* dst, const Line6<P>* l) {
+        if (lane < 13) {
+            Fq v = Fq::zero();
+            const Fq* f = reinterpret_cast<const Fq*>(l);
+            int src_idx = -1;
+            if (lane < 2) src_idx = lane;
+            else if (T::TWIST_IS_D && lane >= 6 && lane < 8) src_idx = 2 + (lane - 6);
+            else if (!T::TWIST_IS_D && lane >= 2 && lane < 4) src_idx = 2 + (lane - 2);
+            else if (lane >= 8 && lane < 10) src_idx = 4 + (lane - 8);
+            if (src_idx >= 0) v = ld_vec(&f[src_idx]);
+            dst[lane] = v;
+        }
+        W::sync();
+    };
+    load_line(acc, &src[lo]);
+    for (u32 i = lo + 1; i < hi; i++) {
+        load_line(cur, &src[i]);
+        W::mul(acc, acc, cur, w);
+    }
+    W::store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+}
+
+// one wave per product: f = Horner over the step products L[prod][s], conjugate when x < 0, final exponentiation
+template <class P>
+__global__ void __launch_bounds__(64)
+k_pair_horner(const Fp12<P>* __restrict__ L, PairSteps st, Fp12<P>* __restrict__ out) {
+    extern __shared__ unsigned char pair_lds[];
+    typedef WaveF12<P> W;
+    typedef Fp<P> Fq;
+    WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
+    Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    Fq* acc = s;
+    Fq* cur = s + 9 * WV_SLOT;
+    const Fp12<P>* src = L + (size_t)blockIdx.x * st.n;
+    W::load(acc, &src[0]);
+    for (int k = 1; k < st.n; k++) {
+        if (st.sq[k]) W::sqr(acc, acc, w);
+        W::load(cur, &src[k]);
+        W::mul(acc, acc, cur, w);
+    }
+    if (TowerParams<P>::X_IS_NEGATIVE) W::conj(acc, acc);
+    W::final_exp(s, w);
+    W::store(&out[blockIdx.x], acc);
+}
+
 // One wave per product: the product of its n Miller values (each lane-group of the wave takes a strided share through
 // the wave multiplier: acc *= in[i]), then the final exponentiation.  in: [count][n] canonical Fq12; out: [count].
 template <class P>

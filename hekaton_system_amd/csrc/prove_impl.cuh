@@ -872,13 +872,14 @@ hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n
     Lane* L = g.lane;
     if (!L) return HK_ERR_DEVICE;
     size_t g1b = sizeof(Affine<Fq>), g2b = sizeof(Affine<Fq2>);
-    size_t need = al256(n_lhs * n * g1b) + al256(n_rhs * n * g2b) + al256(2 * n * count * sizeof(GT)) +
+    size_t mbytes = PairRun<P>::scratch_bytes((u32)n, (u32)count);
+    size_t need = al256(n_lhs * n * g1b) + al256(n_rhs * n * g2b) + al256(mbytes) +
                   2 * al256(count * sizeof(GT)) + 8192;
     HK_TRY(L->reserve(need));
     hipStream_t s = L->stream;
     Affine<Fq>* d1 = L->alloc_n<Affine<Fq>>(n_lhs * n);
     Affine<Fq2>* d2 = L->alloc_n<Affine<Fq2>>(n_rhs * n);
-    GT* miller = L->alloc_n<GT>(2 * n * count);          // Miller values + the ping-pong half of the product tree
+    GT* miller = (GT*)L->alloc(mbytes);                   // lines + per-step tree buffers (or the serial path's Miller values)
     GT* prod = L->alloc_n<GT>(count);
     GT* res = L->alloc_n<GT>(count);
     if (!d1 || !d2 || !miller || !prod || !res) return HK_ERR_NOMEM;
@@ -975,11 +976,29 @@ __global__ void k_finish(const XYZZ<Fq>* __restrict__ res_g1,   // MA, MB1, ML, 
         XYZZ<Fq2> B = ec_madd_ni(ec_madd_ni(ld_vec(&res_g2[0]), ld_vec(&c2[0])), ld_vec(&c2[1]));
         st_vec(out_b, ec_to_affine(B));
     } else {
+        // C = s*A + r*B1 + ML' + MH.  The two variable-base products share ONE doubling chain (Straus, 2-bit joint
+        // windows over the table i*A + j*B1, i, j < 4): 256 doublings + <= 128 additions instead of two 254-step
+        // double-and-add ladders - this kernel is the tail of every proof's latency.
+        __shared__ XYZZ<Fq> tab[16];
         XYZZ<Fq> A = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[0]), ld_vec(&c1[0])), ld_vec(&c1[1]));
         XYZZ<Fq> B1 = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[1]), ld_vec(&c1[2])), ld_vec(&c1[3]));
         Fr r = Fr::from_mont(fr_load(&rs[0])), s = Fr::from_mont(fr_load(&rs[1]));
-        XYZZ<Fq> Cc = ec_mul_limbs(A, s.v);
-        Cc = ec_add_ni(Cc, ec_mul_limbs(B1, r.v));
+        tab[0] = XYZZ<Fq>::inf();
+        tab[1] = B1;
+        tab[2] = ec_dbl_ni(B1);
+        tab[3] = ec_add_ni(tab[2], B1);
+        HK_NOUNROLL for (int i = 1; i < 4; i++) {
+            XYZZ<Fq> row = i == 1 ? A : ec_add_ni(tab[4 * (i - 1)], A);          // i*A
+            tab[4 * i] = row;
+            HK_NOUNROLL for (int j = 1; j < 4; j++) tab[4 * i + j] = ec_add_ni(tab[4 * i + j - 1], B1);
+        }
+        XYZZ<Fq> Cc = XYZZ<Fq>::inf();
+        HK_NOUNROLL for (int w = Fr::N * 16 - 1; w >= 0; w--) {
+            Cc = ec_dbl_ni(ec_dbl_ni(Cc));
+            u32 bs = (s.v[w >> 4] >> (2 * (w & 15))) & 3u, br = (r.v[w >> 4] >> (2 * (w & 15))) & 3u;
+            u32 idx = 4 * bs + br;
+            if (idx) Cc = ec_add_ni(Cc, tab[idx]);
+        }
         Cc = ec_add_ni(Cc, ld_vec(&res_g1[2]));
         Cc = ec_add_ni(Cc, ld_vec(&res_g1[3]));
         st_vec(out_c, ec_to_affine(Cc));

@@ -412,10 +412,14 @@ def prepare_class_host(job):
 
 def prepare_classes_host(jobs, max_workers=None):
     """`prepare_class_host` over several classes in parallel (spawned workers; sequential when there is one)."""
-    if len(jobs) <= 1:
+    import os
+    # under a profiler (rocprofv3 preloads its tool library, which initialises the GPU before Python starts) a worker
+    # spawn would be an exec from a GPU-initialised process: stay in-process there
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or "HSA_TOOLS_LIB" in os.environ or \
+        os.environ.get("HK_NO_SPAWN")
+    if len(jobs) <= 1 or profiled:
         return [prepare_class_host(j) for j in jobs]
     import multiprocessing as mp
-    import os
     n = min(len(jobs), max_workers or max(1, min(8, (os.cpu_count() or 2) // 2)))
     with mp.get_context("spawn").Pool(processes=n) as pool:
         return pool.map(prepare_class_host, jobs)

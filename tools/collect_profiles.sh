@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-2 measurement set (run on the GPU box from the repo root): bench lines, rocprofv3 kernel summaries, PMC traffic.
+# Every rocprofv3 run uses `-- python3 bench.py ...` directly (no env / shell hop) and keeps --pmc runs free of trace
+# domains other than --kernel-trace.
+set -o pipefail
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+O=gpurun_out/prof_r02; mkdir -p $O
+B="--no-cpu-baseline --no-secondary"
+echo "== bench (default line)"; timeout -k 10 500 python bench.py --steps 6 --warmup 2 > $O/bench.json 2> $O/bench.err || exit 1
+echo "== rocprof default bench"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o run -- python3 bench.py $B --steps 2 --warmup 1 > $O/bench_under_rocprof_default.json 2> $O/rocprof_default.err || exit 1
+echo "== rocprof serial streams"
+HK_SERIAL_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_serial -o run -- python3 bench.py $B --single-class --steps 1 --warmup 1 --subcircuits 8 --threads 1 > $O/bench_under_rocprof_serial.json 2> $O/rocprof_serial.err || exit 1
+echo "== pmc fetch"
+HK_SERIAL_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py $B --single-class --steps 1 --warmup 0 --subcircuits 2 --threads 1 --no-verify > /dev/null 2> $O/pmc_fetch.err || exit 1
+echo "== pmc write"
+HK_SERIAL_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py $B --single-class --steps 1 --warmup 0 --subcircuits 2 --threads 1 --no-verify > /dev/null 2> $O/pmc_write.err || exit 1
+echo "== other configs"
+for c in big-merkle-512x64 vm-1024x1024 vkd-256 big-merkle-4x1; do
+  timeout -k 10 500 python bench.py $B --config $c --steps 2 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err || echo "config $c failed"
+done
+find $O -name "*.csv" | head -30
+echo done
