@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_accum0.json from two rocprofv3 counter_collection.csv files (separate --pmc FETCH_SIZE and
+"""a pmc json from two rocprofv3 counter_collection.csv files (separate --pmc FETCH_SIZE and
 --pmc WRITE_SIZE passes of `HK_SERIAL_STREAMS=1 bench.py --steps 1 --warmup 0 --subcircuits 2 --threads 1`).
 usage: pmc_traffic.py <fetch.csv> <write.csv> <out.json>"""
 import csv, json, sys
