@@ -1,0 +1,618 @@
+"""A re-implemented gadget set for the big-merkle subcircuits, with a trace -> assignment witness generator
+(SURVEY.md section 8f row 2).
+
+The reference synthesises `MerkleTreeCircuit` subcircuits with ark-r1cs-std / ark-crypto-primitives gadgets
+(`Sha256Gadget::digest`, `UInt8`, `Boolean::le_bits_to_fp_var`; distributed-prover/src/tree_hash_circuit.rs:98-111,
+313-398) inside the timed region (`prover.rs:70-75`, `node.rs:589-596`).  Those gadget crates are third-party and
+absent, so their constraint LAYOUT cannot be reproduced: PARITY UNPINNED for the matrices.  What is reproduced is the
+FUNCTION of a subcircuit and the shape of its two-stage R1CS:
+
+    stage 0   the subcircuit's portal subtraces: (addr, val) of its time-ordered ROM operations and of its slice of the
+              address-ordered trace (subcircuit_circuit.rs:139-160; rom_transcript.rs:286-306: 2 witnesses per entry)
+    stage 1   instance (1, entry_chal, tr_chal, root); leaf: 64 witnessed bytes -> `ns` iterations of SHA-256 -> digest
+              truncated to 27 bytes, packed little-endian into a field element (vkd/util.rs:17-28 `digest_to_fpvar`)
+              = the value it `set`s; parent: the two `get` values unpacked (`fpvar_to_digest`) -> 54 bytes -> the same
+              chain; root: digest field == root; padding: the chain over 64 zero bytes; every subcircuit: running
+              products of (tr_chal - (addr + entry_chal * val)) over both subtraces (rom_transcript.rs:42-75), equal at
+              the last subcircuit, and value-consistency of equal addresses in the address-ordered slice.
+    NOT reproduced: the Poseidon Merkle membership of the exec-tree leaf (subcircuit_circuit.rs:233-242) and the
+              address-sortedness comparison - both third-party gadget territory; the evals enter and leave as witnesses.
+
+One program, two interpreters (`Tape`): BUILD records the R1CS rows (vectorised, 32 rows per word operation);
+EVAL runs the same program over a BATCH of subcircuits with numpy word arithmetic and emits the assignment directly
+- no constraint-system objects, no per-variable closures: the reference's `generate_constraints` replaced by a
+bit-sliced trace.  Bits leave as one byte each (`assignment_bits`), so a proof's assignment crosses PCIe as ~1 MB
+instead of 32 bytes per variable; `hk`'s Montgomery expansion is a table lookup (0 / 1) plus the few full-width values.
+
+SHA-256 gadget cost here: 26.8 k constraints per compression (XOR 1 constraint / bit, Ch 1, Maj 2, modular additions
+1 + booleanity of result and carry bits).
+"""
+import hashlib
+
+import numpy as np
+
+from .cp_groth16 import CURVE_PARAMS, FrCodec, MultiStageConstraintSynthesizer
+
+K256 = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+IV256 = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+INNER_HASH_SIZE = 27          # bytes of the digest that become the node hash (vkd/sparse_tree.rs:42)
+ONE = 0                       # column of the constant 1
+
+
+class Word:
+    """32 bit positions, least significant first: `cols[i]` = R1CS column of bit i, or -1 for the constant 0
+    (shifts).  `val`: the word's value over the batch (EVAL mode), else None.  `const`: a Python int for constants."""
+    __slots__ = ("cols", "val")
+
+    def __init__(self, cols, val):
+        self.cols, self.val = cols, val
+
+
+def _rotr(w, k):
+    return Word(np.roll(w.cols, -k), None if w.val is None else ((w.val >> np.uint32(k)) | (w.val << np.uint32(32 - k))))
+
+
+def _shr(w, k):
+    cols = np.concatenate([w.cols[k:], np.full(k, -1, np.int64)])
+    return Word(cols, None if w.val is None else (w.val >> np.uint32(k)))
+
+
+class Tape:
+    """BUILD: rows accumulate as (row, col, coeff) triplets per matrix.  EVAL (batch > 0): allocation records."""
+
+    def __init__(self, n_inst, batch=0):
+        self.n_inst = n_inst
+        self.batch = batch
+        self.build = batch == 0
+        self.n_wit = 0
+        self.n_rows = 0
+        self.trip = {m: [] for m in "ABC"}      # lists of (rows, cols, coefs) int64 arrays
+        self.big = []                           # rows with coefficients beyond int64: (A, B, C) as [(coef int, col)]
+        self.consts = {}                        # pinned constant words by value (allocated at first use, both modes)
+        self.bit_records = []                   # EVAL: (first column, bit positions, word values)
+        self.full_records = []                  # EVAL: (column, [python int per batch element])
+
+    # ---- allocation -----------------------------------------------------------------------------------
+    def _alloc(self, k):
+        first = self.n_inst + self.n_wit
+        self.n_wit += k
+        return first
+
+    def _rows(self, k):
+        first = self.n_rows
+        self.n_rows += k
+        return np.arange(first, first + k, dtype=np.int64)
+
+    def _emit(self, m, rows, cols, coefs):
+        self.trip[m].append((np.asarray(rows, np.int64), np.asarray(cols, np.int64), np.asarray(coefs, np.int64)))
+
+    def alloc_bits(self, pos, val, boolean):
+        """New witness bits for the bit positions `pos` of the word value `val`; booleanity rows b * (1 - b) = 0 when
+        the bits are not boolean by construction.  Returns their columns."""
+        k = len(pos)
+        first = self._alloc(k)
+        cols = np.arange(first, first + k, dtype=np.int64)
+        if self.build:
+            if boolean:
+                r = self._rows(k)
+                self._emit("A", r, cols, np.ones(k, np.int64))
+                self._emit("B", np.concatenate([r, r]), np.concatenate([np.full(k, ONE), cols]),
+                           np.concatenate([np.ones(k, np.int64), -np.ones(k, np.int64)]))
+        else:
+            self.bit_records.append((first, np.asarray(pos, np.uint32), val))
+        return cols
+
+    def alloc_word(self, val, boolean=True):
+        return Word(self.alloc_bits(np.arange(32), val, boolean), val)
+
+    def alloc_full(self, vals):
+        """One full-width witness; vals: list of Python ints (EVAL) or None."""
+        col = self._alloc(1)
+        if not self.build:
+            self.full_records.append((col, vals))
+        return col
+
+    # ---- bit gadgets (vectorised over the 32 positions of a word) -----------------------------------------
+    def xor(self, x, y):
+        """x ^ y; positions where one side is the constant 0 pass the other side through without a constraint."""
+        both = (x.cols >= 0) & (y.cols >= 0)
+        val = None if self.build else x.val ^ y.val
+        pos = np.nonzero(both)[0]
+        new = self.alloc_bits(pos, val, boolean=False)
+        cols = np.where(x.cols >= 0, x.cols, y.cols).copy()
+        cols[pos] = new
+        if self.build and len(pos):
+            k = len(pos)
+            r = self._rows(k)
+            xa, ya = x.cols[pos], y.cols[pos]
+            self._emit("A", r, xa, np.full(k, 2))                                  # (2 x) * (y) = x + y - t
+            self._emit("B", r, ya, np.ones(k, np.int64))
+            self._emit("C", np.concatenate([r, r, r]), np.concatenate([xa, ya, new]),
+                       np.concatenate([np.ones(k, np.int64), np.ones(k, np.int64), -np.ones(k, np.int64)]))
+        return Word(cols, val)
+
+    def xor3(self, x, y, z):
+        return self.xor(self.xor(x, y), z)
+
+    def ch(self, e, f, g):
+        """(e & f) ^ (~e & g):  e * (f - g) = ch - g."""
+        val = None if self.build else (e.val & f.val) ^ (~e.val & g.val)
+        w = self.alloc_word(val, boolean=False)
+        if self.build:
+            r = self._rows(32)
+            self._emit("A", r, e.cols, np.ones(32, np.int64))
+            self._emit("B", np.concatenate([r, r]), np.concatenate([f.cols, g.cols]),
+                       np.concatenate([np.ones(32, np.int64), -np.ones(32, np.int64)]))
+            self._emit("C", np.concatenate([r, r]), np.concatenate([w.cols, g.cols]),
+                       np.concatenate([np.ones(32, np.int64), -np.ones(32, np.int64)]))
+        return w
+
+    def maj(self, a, b, c):
+        """t = a * b;  c * (a + b - 2 t) = maj - t."""
+        tv = None if self.build else a.val & b.val
+        t = self.alloc_word(tv, boolean=False)
+        val = None if self.build else (a.val & b.val) ^ (a.val & c.val) ^ (b.val & c.val)
+        w = self.alloc_word(val, boolean=False)
+        if self.build:
+            o = np.ones(32, np.int64)
+            r = self._rows(32)
+            self._emit("A", r, a.cols, o); self._emit("B", r, b.cols, o); self._emit("C", r, t.cols, o)
+            r = self._rows(32)
+            self._emit("A", r, c.cols, o)
+            self._emit("B", np.concatenate([r, r, r]), np.concatenate([a.cols, b.cols, t.cols]), np.concatenate([o, o, -2 * o]))
+            self._emit("C", np.concatenate([r, r]), np.concatenate([w.cols, t.cols]), np.concatenate([o, -o]))
+        return w
+
+    def add(self, words, const=0):
+        """Sum of the words (and a constant) mod 2^32: result bits and carry bits are witnessed (boolean) and one
+        linear row ties them: (sum_j sum_i 2^i w_j[i] + const) * 1 = sum_i 2^i r[i] + 2^32 * carry."""
+        k = len(words) + (1 if const else 0)
+        cbits = max(1, (k - 1).bit_length())
+        if self.build:
+            tot = None
+        else:
+            tot = np.full(self.batch, const, np.uint64)
+            for w in words:
+                tot = tot + w.val.astype(np.uint64)
+        r = self.alloc_word(None if self.build else (tot & np.uint64(0xffffffff)).astype(np.uint32))
+        carry = self.alloc_bits(np.arange(cbits), None if self.build else (tot >> np.uint64(32)).astype(np.uint32), True)
+        if self.build:
+            row = self._rows(1)[0]
+            pw = (1 << np.arange(32, dtype=np.int64))
+            cols, coefs = [], []
+            for w in words:
+                nz = w.cols >= 0
+                cols.append(w.cols[nz]); coefs.append(pw[nz])
+            if const:
+                cols.append(np.array([ONE])); coefs.append(np.array([const], np.int64))
+            cols, coefs = np.concatenate(cols), np.concatenate(coefs)
+            self._emit("A", np.full(len(cols), row), cols, coefs)
+            self._emit("B", [row], [ONE], [1])
+            self._emit("C", np.full(32 + cbits, row), np.concatenate([r.cols, carry]),
+                       np.concatenate([pw, (1 << (32 + np.arange(cbits, dtype=np.int64)))]))
+        return r
+
+    def big_row(self, a, b, c):
+        """One row with arbitrary (Python int) coefficients: lists of (coef, col)."""
+        if self.build:
+            row = self._rows(1)[0]
+            self.big.append((row, a, b, c))
+
+    # ---- SHA-256 ---------------------------------------------------------------------------------------
+    def sha256_compress(self, state, block):
+        """state: 8 Words or ints (the IV); block: 16 Words (big-endian message words).  Returns 8 Words."""
+        w = list(block)
+        for t in range(16, 64):
+            s0 = self.xor3(_rotr(w[t - 15], 7), _rotr(w[t - 15], 18), _shr(w[t - 15], 3))
+            s1 = self.xor3(_rotr(w[t - 2], 17), _rotr(w[t - 2], 19), _shr(w[t - 2], 10))
+            w.append(self.add([s1, w[t - 7], s0, w[t - 16]]))
+        first = isinstance(state[0], int)
+        if first:                          # IV: witnessed constant words (booleanity rows pin nothing; equality rows do)
+            st = [self.const_word(v) for v in state]
+        else:
+            st = list(state)
+        a, b, c, d, e, f, g, h = st
+        for t in range(64):
+            S1 = self.xor3(_rotr(e, 6), _rotr(e, 11), _rotr(e, 25))
+            chv = self.ch(e, f, g)
+            S0 = self.xor3(_rotr(a, 2), _rotr(a, 13), _rotr(a, 22))
+            mj = self.maj(a, b, c)
+            new_e = self.add([d, h, S1, chv, w[t]], K256[t])
+            new_a = self.add([h, S1, chv, w[t], S0, mj], K256[t])
+            a, b, c, d, e, f, g, h = new_a, a, b, c, new_e, e, f, g
+        return [self.add([x, y]) for x, y in zip(st, [a, b, c, d, e, f, g, h])]
+
+    def const_word(self, v):
+        """A word whose 32 bits are pinned to the constant v: 32 rows b * 1 = bit (one allocation per distinct value)."""
+        if v in self.consts:
+            return self.consts[v]
+        val = None if self.build else np.full(self.batch, v, np.uint32)
+        w = self.alloc_word(val, boolean=False)
+        if self.build:
+            r = self._rows(32)
+            o = np.ones(32, np.int64)
+            self._emit("A", r, w.cols, o)
+            self._emit("B", r, np.full(32, ONE), o)
+            bits = (v >> np.arange(32)) & 1
+            nz = np.nonzero(bits)[0]
+            self._emit("C", r[nz], np.full(len(nz), ONE), np.ones(len(nz), np.int64))
+        self.consts[v] = w
+        return w
+
+    def sha256_bytes(self, byte_words_be, n_bytes):
+        """SHA-256 of an n_bytes message given as big-endian 32-bit Words (n_bytes % 4 may be non-zero only through
+        pre-packed words): pads (0x80, zeros, 64-bit length) and compresses.  Returns the 8 digest Words."""
+        total = ((n_bytes + 9 + 63) // 64) * 64
+        n_words = total // 4
+        msg = list(byte_words_be)
+        assert len(msg) * 4 >= n_bytes
+        # the padding words are constants: allocate them as pinned constant words
+        pad_bytes = bytearray(total)
+        pad_bytes[n_bytes] = 0x80
+        pad_bytes[-8:] = (8 * n_bytes).to_bytes(8, "big")
+        full_words = n_bytes // 4
+        assert n_bytes % 4 == 0 or len(msg) == full_words + 1
+        words = msg[:full_words]
+        if n_bytes % 4:
+            words.append(msg[full_words])       # caller already merged the 0x80 marker into the partial word
+        for k in range(len(words), n_words):
+            words.append(self.const_word(int.from_bytes(pad_bytes[4 * k:4 * k + 4], "big")))
+        state = IV256
+        for blk in range(total // 64):
+            state = self.sha256_compress(state, words[16 * blk:16 * blk + 16])
+        return state
+
+    # ---- finishing -------------------------------------------------------------------------------------
+    def csr(self, fc):
+        """BUILD: the three matrices as (row_ptr u64, col u32, val Montgomery bytes)."""
+        r_mod = fc.r
+        out = []
+        for m in "ABC":
+            rows = np.concatenate([t[0] for t in self.trip[m]]) if self.trip[m] else np.zeros(0, np.int64)
+            cols = np.concatenate([t[1] for t in self.trip[m]]) if self.trip[m] else np.zeros(0, np.int64)
+            coefs = np.concatenate([t[2] for t in self.trip[m]]) if self.trip[m] else np.zeros(0, np.int64)
+            big_rows, big_cols, big_vals = [], [], []
+            idx = "ABC".index(m)
+            for entry in self.big:
+                for coef, col in entry[1 + idx]:
+                    big_rows.append(entry[0]); big_cols.append(col); big_vals.append(coef % r_mod)
+            uniq, inv = np.unique(coefs, return_inverse=True)
+            table = [int(u) % r_mod for u in uniq.tolist()] + big_vals
+            vidx = np.concatenate([inv, len(uniq) + np.arange(len(big_vals))]).astype(np.int64)
+            rows = np.concatenate([rows, np.array(big_rows, np.int64)])
+            cols = np.concatenate([cols, np.array(big_cols, np.int64)])
+            order = np.argsort(rows, kind="stable")
+            rows, cols, vidx = rows[order], cols[order], vidx[order]
+            row_ptr = np.zeros(self.n_rows + 1, np.uint64)
+            row_ptr[1:] = np.cumsum(np.bincount(rows, minlength=self.n_rows))
+            tab = fc.enc(table).reshape(len(table), fc.nb)
+            out.append((row_ptr, cols.astype(np.uint32), np.ascontiguousarray(tab[vidx]).ravel(), vidx, table))
+        return out
+
+    def assignment_bits(self, n_v):
+        """EVAL: (batch, n_v) uint8 with every bit variable's value (column 0 = 1; full-width columns left 0)."""
+        out = np.zeros((self.batch, n_v), np.uint8)
+        out[:, ONE] = 1
+        for first, pos, val in self.bit_records:
+            out[:, first:first + len(pos)] = ((val[:, None] >> pos[None, :]) & np.uint32(1)).astype(np.uint8)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
+    """One proving-key class of the re-implemented big-merkle circuit.  kind: "leaf" | "parent" | "root" | "padding";
+    `first` marks subcircuit 0 (evals pinned to 1), `last` the final subcircuit (time eval == addr eval)."""
+    N_INST = 4
+
+    def __init__(self, curve, kind, ns, n_portals, first=False, last=False):
+        assert kind in ("leaf", "parent", "root", "padding")
+        self.curve, self.kind, self.ns, self.np_, self.first, self.last = curve, kind, ns, n_portals, first, last
+        self.r = CURVE_PARAMS[curve]["r"]
+        self.fc = FrCodec(curve)
+        self.n_time = self.n_addr = n_portals
+        self.n0 = 2 * (self.n_time + self.n_addr)
+        t = Tape(self.N_INST)
+        self._program(t, None)
+        self.tape = t
+        self.n_c = t.n_rows
+        self.n_wit = t.n_wit
+        self.n_v = self.N_INST + t.n_wit
+        self._csr = None
+        self._batch = None
+
+    # ---- the program: identical in BUILD and EVAL --------------------------------------------------------
+    def _program(self, t, inp):
+        """inp (EVAL): dict with numpy / int inputs for the batch, see `witness_batch`."""
+        ev = not t.build
+        B = t.batch
+        ni = self.N_INST
+        ENTRY, TR, ROOT = 1, 2, 3
+        # ---- stage 0: (addr, val) of every time-ordered and address-ordered entry
+        time_e = [(t.alloc_full(inp["time"][k][0] if ev else None), t.alloc_full(inp["time"][k][1] if ev else None))
+                  for k in range(self.n_time)]
+        addr_e = [(t.alloc_full(inp["addr"][k][0] if ev else None), t.alloc_full(inp["addr"][k][1] if ev else None))
+                  for k in range(self.n_addr)]
+        assert t.n_wit == self.n0
+        r_mod = self.r
+        # ---- stage 1
+        # running evaluations (rom_transcript.rs:42-75): eval' = eval * (tr_chal - (addr + entry_chal * val))
+        def running(entries, start_vals, key):
+            ev_col = t.alloc_full(start_vals if ev else None)
+            cur = start_vals
+            if self.first:
+                t.big_row([(1, ev_col)], [(1, ONE)], [(1, ONE)])                    # subcircuit 0: eval = 1
+            for k, (a_col, v_col) in enumerate(entries):
+                if ev:
+                    ech, tr = inp["entry_chal"], inp["tr_chal"]
+                    e_vals = [(int(a) + ech * int(v)) % r_mod for a, v in zip(inp[key][k][0], inp[key][k][1])]
+                    nxt = [c * ((tr - e) % r_mod) % r_mod for c, e in zip(cur, e_vals)]
+                else:
+                    e_vals = nxt = None
+                e_col = t.alloc_full(e_vals)
+                n_col = t.alloc_full(nxt)
+                t.big_row([(1, ENTRY)], [(1, v_col)], [(1, e_col), (r_mod - 1, a_col)])
+                t.big_row([(1, ev_col)], [(1, TR), (r_mod - 1, e_col)], [(1, n_col)])
+                ev_col, cur = n_col, nxt
+            return ev_col, cur
+        t_final, t_vals = running(time_e, inp["time_eval0"] if ev else None, "time")
+        a_final, a_vals = running(addr_e, inp["addr_eval0"] if ev else None, "addr")
+        if self.last:
+            t.big_row([(1, t_final), (r_mod - 1, a_final)], [(1, ONE)], [])
+        # value consistency of equal addresses in the address-ordered slice:
+        #   (addr' - addr) * inv = 1 - same ;  same * (addr' - addr) = 0 ;  same * (val' - val) = 0
+        for k in range(1, self.n_addr):
+            (a0, v0), (a1, v1) = addr_e[k - 1], addr_e[k]
+            if ev:
+                d = [(int(x) - int(y)) % r_mod for x, y in zip(inp["addr"][k][0], inp["addr"][k - 1][0])]
+                inv = [pow(x, -1, r_mod) if x else 0 for x in d]
+                same = [0 if x else 1 for x in d]
+            else:
+                inv = same = None
+            inv_c, same_c = t.alloc_full(inv), t.alloc_full(same)
+            t.big_row([(1, a1), (r_mod - 1, a0)], [(1, inv_c)], [(1, ONE), (r_mod - 1, same_c)])
+            t.big_row([(1, same_c)], [(1, a1), (r_mod - 1, a0)], [])
+            t.big_row([(1, same_c)], [(1, v1), (r_mod - 1, v0)], [])
+        # ---- the hash chain
+        if self.kind in ("leaf", "padding"):
+            # 64 witnessed bytes as 16 big-endian words (bits boolean)
+            words = [t.alloc_word(inp["leaf_words"][:, k] if ev else None) for k in range(16)]
+            if self.kind == "padding":
+                zero = t.const_word(0)       # EMPTY_LEAF: pin the input to zero through one pinned word
+                for w in words:
+                    self._enforce_word_eq(t, w, zero)
+            digest = t.sha256_bytes(words, 64)
+        else:
+            # two `get`s: unpack each value (216 bits, little-endian per byte as `fpvar_to_digest`) into 27 bytes
+            words = self._unpack_children(t, time_e, inp)
+            digest = t.sha256_bytes(words, 54)
+        for _ in range(self.ns - 1):
+            digest = t.sha256_bytes(digest, 32)
+        # digest -> field: first 27 bytes, each byte's bits little-endian, bytes in order (digest_to_fpvar)
+        terms = self._digest_field_terms(digest)
+        if self.kind == "leaf" or self.kind == "parent":
+            out_col = time_e[-1][1]                        # the `set` is the subcircuit's last time-ordered operation
+            t.big_row(terms, [(1, ONE)], [(1, out_col)])
+        elif self.kind == "root":
+            t.big_row(terms, [(1, ONE)], [(1, ROOT)])
+        return digest
+
+    @staticmethod
+    def _enforce_word_eq(t, w, z):
+        if t.build:
+            r = t._rows(32)
+            o = np.ones(32, np.int64)
+            t._emit("A", np.concatenate([r, r]), np.concatenate([w.cols, z.cols]), np.concatenate([o, -o]))
+            t._emit("B", r, np.full(32, ONE), o)
+
+    @staticmethod
+    def _digest_field_terms(digest):
+        """[(2^k, col)] with k the position `digest_to_fpvar` gives the bit: byte j (big-endian byte j of the digest),
+        bit b (little-endian within the byte) -> 8 j + b."""
+        terms = []
+        for j in range(INNER_HASH_SIZE):
+            w = digest[j // 4]
+            shift = 8 * (3 - j % 4)                        # byte j%4 of a big-endian word
+            for b in range(8):
+                terms.append((1 << (8 * j + b), int(w.cols[shift + b])))
+        return terms
+
+    def _unpack_children(self, t, time_e, inp):
+        """The two children hashes (values of the first two time-ordered entries) as 54 message bytes in 14 big-endian
+        words; the last word carries the 0x80 padding marker in its free bytes."""
+        ev = not t.build
+        byte_cols, byte_vals = [], []
+        for child in range(2):
+            v_col = time_e[child][1]
+            if ev:
+                vals = inp["time"][child][1]
+                raw = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), np.uint8).reshape(t.batch, 32)
+            terms = []
+            for j in range(INNER_HASH_SIZE):
+                bv = raw[:, j].astype(np.uint32) if ev else None
+                cols = t.alloc_bits(np.arange(8), bv, True)
+                byte_cols.append(cols); byte_vals.append(bv)
+                terms += [(1 << (8 * j + b), int(cols[b])) for b in range(8)]
+            t.big_row(terms, [(1, ONE)], [(1, v_col)])      # the unpacked bits re-pack to the `get` value
+        words = []
+        for k in range(14):
+            cols = np.full(32, -1, np.int64)
+            val = np.zeros(t.batch, np.uint32) if ev else None
+            for bi in range(4):
+                j = 4 * k + bi
+                if j < 54:
+                    cols[8 * (3 - bi):8 * (3 - bi) + 8] = byte_cols[j]
+                    if ev:
+                        val |= byte_vals[j] << np.uint32(8 * (3 - bi))
+            if k == 13:                                      # bytes 52, 53 then 0x80, 0x00: the marker bit is a pinned 1
+                one_bit = t.alloc_bits(np.arange(1), np.ones(t.batch, np.uint32) if ev else None, False)
+                t.big_row([(1, int(one_bit[0]))], [(1, ONE)], [(1, ONE)])
+                cols[8 * 1 + 7] = one_bit[0]                 # byte 2 of the word = 0x80: its bit 7
+                if ev:
+                    val |= np.uint32(0x8000)
+            words.append(Word(cols, val))
+        return words
+
+    # ---- MultiStageConstraintSynthesizer -------------------------------------------------------------------
+    def total_num_stages(self):
+        return 2
+
+    def generate_constraints(self, stage, cs):
+        z = self._setup_assignment()
+        ni = self.N_INST
+        cs.initialize_stage()
+        if stage == 0:
+            cs.witness_assignment.extend(z[ni:ni + self.n0])
+        else:
+            cs.instance_assignment.extend(z[1:ni])
+            cs.witness_assignment.extend(z[ni + self.n0:])
+            cs._n_constraints += self.n_c
+        cs.finalize_stage()
+
+    def _setup_assignment(self):
+        if getattr(self, "_setup_z", None) is None:
+            w = example_witness(self, seed=0)
+            self._setup_z = self.assignment_ints(w)[0]
+        return self._setup_z
+
+    def csr(self, fc):
+        if self._csr is None:
+            self._csr = self.tape.csr(fc)
+        return tuple((rp, col, val) for rp, col, val, _vi, _tab in self._csr)
+
+    def qap_evaluate(self, t_pt):
+        """instance_map_with_evaluation over the tape's rows (generator.rs:75-76)."""
+        p = CURVE_PARAMS[self.curve]
+        r, ni, n_c = self.r, self.N_INST, self.n_c
+        m, log_m = 1, 0
+        while m < n_c + ni:
+            m *= 2
+            log_m += 1
+        w = pow(pow(p["gen"], (r - 1) >> p["two_adicity"], r), 1 << (p["two_adicity"] - log_m), r)
+        zt = (pow(t_pt, m, r) - 1) % r
+        from .cp_groth16 import _batch_inverse
+        wi = [1] * m
+        for i in range(1, m):
+            wi[i] = wi[i - 1] * w % r
+        den = _batch_inverse([m * (t_pt - x) % r for x in wi], r)
+        u = [zt * x % r * d % r for x, d in zip(wi, den)]
+        self.csr(self.fc)
+        outs = []
+        for (rp, col, _val, vidx, table) in self._csr:
+            acc = [0] * self.n_v
+            rp_l, col_l, vi_l = rp.tolist(), col.tolist(), vidx.tolist()
+            for i in range(n_c):
+                ui = u[i]
+                for k in range(rp_l[i], rp_l[i + 1]):
+                    acc[col_l[k]] += ui * table[vi_l[k]]
+            outs.append([x % r for x in acc])
+        a, b, c = outs
+        for j in range(ni):
+            a[j] = (a[j] + u[n_c + j]) % r
+        return a, b, c, zt, m
+
+    # ---- witness generation --------------------------------------------------------------------------------
+    def witness_batch(self, inputs):
+        """inputs: list of per-subcircuit dicts (see `example_witness`).  Runs the program in EVAL mode over the whole
+        batch.  Returns (bits uint8 (batch, n_v), full-width {column: [ints]}, digests list of 32-byte strings)."""
+        B = len(inputs)
+        inp = dict(entry_chal=None, tr_chal=None)
+        inp["entry_chal"], inp["tr_chal"] = inputs[0]["entry_chal"], inputs[0]["tr_chal"]
+        assert all(i["entry_chal"] == inp["entry_chal"] and i["tr_chal"] == inp["tr_chal"] for i in inputs)
+        for key, n in (("time", self.n_time), ("addr", self.n_addr)):
+            inp[key] = [([i[key][k][0] for i in inputs], [i[key][k][1] for i in inputs]) for k in range(n)]
+        inp["time_eval0"] = [i["time_eval0"] for i in inputs]
+        inp["addr_eval0"] = [i["addr_eval0"] for i in inputs]
+        if self.kind in ("leaf", "padding"):
+            leaves = np.frombuffer(b"".join(i["leaf"] for i in inputs), np.uint8).reshape(B, 64)
+            inp["leaf_words"] = leaves.reshape(B, 16, 4).astype(np.uint32) @ np.array([1 << 24, 1 << 16, 1 << 8, 1], np.uint32)
+        t = Tape(self.N_INST, batch=B)
+        digest = self._program(t, inp)
+        assert t.n_wit == self.n_wit
+        bits = t.assignment_bits(self.n_v)
+        full = {col: vals for col, vals in t.full_records}
+        dig = np.stack([w.val for w in digest], axis=1)            # (B, 8) uint32 big-endian words
+        digests = [b"".join(int(x).to_bytes(4, "big") for x in row) for row in dig]
+        return bits, full, digests
+
+    def assignment_ints(self, inputs):
+        """Full assignments as Python ints (tests / setup)."""
+        inputs = inputs if isinstance(inputs, list) else [inputs]
+        bits, full, _ = self.witness_batch(inputs)
+        out = []
+        for b in range(len(inputs)):
+            z = bits[b].astype(np.int64).tolist()
+            z[1], z[2], z[3] = inputs[b]["entry_chal"], inputs[b]["tr_chal"], inputs[b]["root"]
+            for col, vals in full.items():
+                z[col] = int(vals[b]) % self.r
+            out.append(z)
+        return out
+
+    def assignment_bytes(self, inputs):
+        """Montgomery bytes of the full assignments, (batch, n_v * 32): bits through a two-entry table."""
+        inputs = inputs if isinstance(inputs, list) else [inputs]
+        bits, full, _ = self.witness_batch(inputs)
+        fc = self.fc
+        tab = fc.enc([0, 1]).reshape(2, fc.nb)
+        out = tab[bits]                                           # (B, n_v, nb)
+        for b in range(len(inputs)):
+            cols = [1, 2, 3] + list(full.keys())
+            vals = [inputs[b]["entry_chal"], inputs[b]["tr_chal"], inputs[b]["root"]] + [int(v[b]) for v in full.values()]
+            out[b, cols] = fc.enc(vals).reshape(len(cols), fc.nb)
+        return out.reshape(len(inputs), self.n_v * fc.nb)
+
+
+def node_hash_field(digest):
+    """`digest_to_fpvar` on the host: first 27 bytes, byte j bit b -> 2^(8j + b): the little-endian integer."""
+    return int.from_bytes(digest[:INNER_HASH_SIZE], "little")
+
+
+def iterated_sha256(data, ns):
+    d = data
+    for _ in range(ns):
+        d = hashlib.sha256(d).digest()
+    return d
+
+
+def example_witness(circ, seed=0, entry_chal=None, tr_chal=None):
+    """A consistent input for one subcircuit of class `circ` (tests, setup): random leaf / children, the portal entries
+    the program expects (parents: two gets then the set; leaves: placeholders then the set), random starting evals
+    (1 for the first subcircuit), and the root the chain produces."""
+    import random
+    rnd = random.Random(seed)
+    r = circ.r
+    ech = entry_chal if entry_chal is not None else rnd.randrange(r)
+    tr = tr_chal if tr_chal is not None else rnd.randrange(r)
+    w = dict(entry_chal=ech, tr_chal=tr)
+    n = circ.n_time
+    time = [(rnd.randrange(1 << 20), 0) for _ in range(n)]          # placeholder gets of address 0's value 0
+    if circ.kind in ("leaf", "padding"):
+        w["leaf"] = bytes(64) if circ.kind == "padding" else bytes(rnd.randrange(256) for _ in range(64))
+        out = node_hash_field(iterated_sha256(w["leaf"], circ.ns))
+    else:
+        kids = [bytes(rnd.randrange(256) for _ in range(INNER_HASH_SIZE)) for _ in range(2)]
+        for k in range(2):
+            time[k] = (rnd.randrange(1 << 20), int.from_bytes(kids[k], "little"))
+        out = node_hash_field(iterated_sha256(kids[0] + kids[1], circ.ns))
+    if circ.kind in ("leaf", "parent"):
+        time[-1] = (rnd.randrange(1 << 20), out)
+    w["time"] = time
+    # an address-ordered slice: sorted by address, duplicates carry equal values
+    addr = sorted((rnd.randrange(1 << 20), rnd.randrange(r)) for _ in range(circ.n_addr))
+    if circ.n_addr > 1:
+        addr[1] = addr[0]
+    w["addr"] = addr
+    w["time_eval0"] = 1 if circ.first else rnd.randrange(1, r)
+    w["addr_eval0"] = 1 if circ.first else rnd.randrange(1, r)
+    w["root"] = out if circ.kind == "root" else rnd.randrange(r)
+    if circ.last:
+        # the permutation check needs equal final evals: make the two traces the same multiset and the starts equal
+        w["addr"] = sorted(time)
+        w["addr_eval0"] = w["time_eval0"]
+    return w

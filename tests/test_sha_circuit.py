@@ -1,0 +1,66 @@
+"""CPU: the re-implemented big-merkle gadget set (hekaton_system_amd/sha_circuit.py): the trace -> assignment generator
+computes real SHA-256 chains (checked against hashlib), and the assignment it emits satisfies every row of the R1CS the
+same program builds, for every subcircuit kind; tampering breaks it."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from hekaton_system_amd.cp_groth16 import FrCodec
+from hekaton_system_amd.sha_circuit import (INNER_HASH_SIZE, ShaMerkleSubcircuit, example_witness, iterated_sha256,
+                                            node_hash_field)
+
+
+def _check_r1cs(circ, z):
+    fc = circ.fc
+    r = circ.r
+    vals = []
+    for (rp, col, _val, vidx, table) in circ._csr or (circ.csr(fc) and circ._csr):
+        rp, col, vidx = rp.tolist(), col.tolist(), vidx.tolist()
+        out = []
+        for i in range(circ.n_c):
+            acc = 0
+            for k in range(rp[i], rp[i + 1]):
+                acc += table[vidx[k]] * z[col[k]]
+            out.append(acc % r)
+        vals.append(out)
+    bad = [i for i in range(circ.n_c) if vals[0][i] * vals[1][i] % r != vals[2][i]]
+    return bad
+
+
+@pytest.mark.parametrize("kind,ns,first,last", [("leaf", 1, True, False), ("leaf", 2, False, False), ("parent", 1, False, False),
+                                                ("root", 2, False, False), ("padding", 1, False, True)])
+def test_generated_assignment_satisfies_the_r1cs(kind, ns, first, last):
+    circ = ShaMerkleSubcircuit("bn254", kind, ns, n_portals=4, first=first, last=last)
+    circ.csr(circ.fc)
+    ws = [example_witness(circ, seed=s, entry_chal=12345, tr_chal=67890) for s in (1, 2, 3)]
+    zs = circ.assignment_ints(ws)
+    assert len(zs[0]) == circ.n_v and circ.n_c > 26000 * ns
+    for z in zs[:2]:
+        assert _check_r1cs(circ, z) == []
+    # the chain is real SHA-256
+    _bits, _full, digests = circ.witness_batch(ws)
+    for w, d in zip(ws, digests):
+        if kind in ("leaf", "padding"):
+            assert d == iterated_sha256(w["leaf"], ns)
+        else:
+            kids = b"".join(int(w["time"][k][1]).to_bytes(INNER_HASH_SIZE, "little") for k in range(2))
+            assert d == iterated_sha256(kids, ns)
+        if kind in ("leaf", "parent"):
+            assert w["time"][-1][1] == node_hash_field(d)
+    # a flipped bit somewhere in the middle of the trace violates some row
+    z = list(zs[0])
+    mid = circ.N_INST + circ.n0 + (circ.n_wit - circ.n0) // 2
+    z[mid] = 1 - z[mid] if z[mid] in (0, 1) else z[mid] + 1
+    assert _check_r1cs(circ, z) != []
+
+
+def test_montgomery_bytes_match_the_ints():
+    circ = ShaMerkleSubcircuit("bn254", "leaf", 1, n_portals=4)
+    w = example_witness(circ, seed=9)
+    z = circ.assignment_ints(w)[0]
+    zb = circ.assignment_bytes(w)[0]
+    fc = FrCodec("bn254")
+    assert fc.dec(zb[:40 * 32]) == z[:40]
+    assert fc.dec(zb[-8 * 32:]) == z[-8:]
+    assert hashlib.sha256(b"abc").hexdigest().startswith("ba7816bf")
