@@ -517,6 +517,23 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
             a[j] = (a[j] + u[n_c + j]) % r
         return a, b, c, zt, m
 
+    # ---- the workload interface bench.py / tests use for synthetic classes (workload.SyntheticSubcircuit) ----------
+    def set_witness_seed(self, seed):
+        self._cur = example_witness(self, seed=seed, entry_chal=0x1234567, tr_chal=0x7654321)
+        self._cur_z = None
+
+    def assignment_ints_current(self):
+        if self._cur_z is None:
+            self._cur_z = self.assignment_ints(self._cur)[0]
+        return self._cur_z
+
+    def full_assignment_bytes(self, cs=None):
+        return self.assignment_bytes(self._cur)[0]
+
+    def stage0_witness_bytes(self):
+        z = self.assignment_ints_current()
+        return self.fc.enc(z[self.N_INST:self.N_INST + self.n0])
+
     # ---- witness generation --------------------------------------------------------------------------------
     def witness_batch(self, inputs):
         """inputs: list of per-subcircuit dicts (see `example_witness`).  Runs the program in EVAL mode over the whole
@@ -616,3 +633,93 @@ def example_witness(circ, seed=0, entry_chal=None, tr_chal=None):
         w["addr"] = sorted(time)
         w["addr_eval0"] = w["time_eval0"]
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class ShaMerkleJob:
+    """Witness generation for a WHOLE big-merkle job (what `MerkleTreeCircuit::get_portal_subtraces` +
+    `generate_constraints(0..n)` produce in the reference, tree_hash_circuit.rs:313-398,400-470): the tree of iterated
+    SHA-256 hashes over `n/2` leaves, the ROM trace of every `set` / `get`, its address-sorted copy, the slice of both
+    each subcircuit commits to in stage 0, and the running evaluations that thread through the subcircuits.
+
+    Subcircuit order = the reference's (`subcircuit_idx_to_node_idx`): leaves, then parents level by level, the root at
+    n - 2, the padding subcircuit at n - 1.  Time-ordered operations of a subcircuit (n_portals of them):
+        leaf     placeholder gets ..., set(node hash)            parent   get(left), get(right), placeholders ..., set
+        root     get(left), get(right), placeholders ...         padding  placeholders ...
+    address 0 = the placeholder portal (value 0), address 1 + j = the hash of the node proved by subcircuit j."""
+
+    def __init__(self, curve, n_subcircuits, ns, n_portals, leaves, entry_chal, tr_chal):
+        n = n_subcircuits
+        assert n >= 4 and n & (n - 1) == 0 and len(leaves) == n // 2 and n_portals >= 3
+        self.curve, self.n, self.ns, self.np_ = curve, n, ns, n_portals
+        self.r = CURVE_PARAMS[curve]["r"]
+        self.entry_chal, self.tr_chal = entry_chal % self.r, tr_chal % self.r
+        nl = n // 2
+        # node j (subcircuit order) -> children; hashes
+        self.kind = ["leaf"] * nl + ["parent"] * (n - 2 - nl) + ["root", "padding"]
+        self.children = {}
+        level_start, width, j = 0, nl, nl
+        while width > 1:
+            for k in range(width // 2):
+                self.children[j] = (level_start + 2 * k, level_start + 2 * k + 1)
+                j += 1
+            level_start += width
+            width //= 2
+        assert j == n - 1
+        self.leaves = list(leaves)
+        self.digest = [None] * n
+        for i in range(nl):
+            self.digest[i] = iterated_sha256(self.leaves[i], ns)
+        for jj in range(nl, n - 1):
+            l, rr = self.children[jj]
+            self.digest[jj] = iterated_sha256(self.digest[l][:INNER_HASH_SIZE] + self.digest[rr][:INNER_HASH_SIZE], ns)
+        self.digest[n - 1] = iterated_sha256(bytes(64), ns)
+        self.root = node_hash_field(self.digest[n - 2])
+        val = lambda jj: node_hash_field(self.digest[jj])
+        # time-ordered trace
+        self.time = []
+        for idx in range(n):
+            ops = []
+            if self.kind[idx] in ("parent", "root"):
+                l, rr = self.children[idx]
+                ops += [(1 + l, val(l)), (1 + rr, val(rr))]
+            n_set = 1 if self.kind[idx] in ("leaf", "parent") else 0
+            ops += [(0, 0)] * (n_portals - len(ops) - n_set)
+            if n_set:
+                ops.append((1 + idx, val(idx)))
+            assert len(ops) == n_portals
+            self.time.append(ops)
+        flat = [e for ops in self.time for e in ops]
+        order = sorted(range(len(flat)), key=lambda k: (flat[k][0], k))
+        srt = [flat[k] for k in order]
+        self.addr = [srt[idx * n_portals:(idx + 1) * n_portals] for idx in range(n)]
+        # running evaluations entering every subcircuit
+        r, ech, tr = self.r, self.entry_chal, self.tr_chal
+        step = lambda cur, e: cur * ((tr - (e[0] + ech * e[1])) % r) % r
+        self.time_eval0, self.addr_eval0 = [1], [1]
+        for idx in range(n):
+            t, a = self.time_eval0[-1], self.addr_eval0[-1]
+            for e in self.time[idx]:
+                t = step(t, e)
+            for e in self.addr[idx]:
+                a = step(a, e)
+            self.time_eval0.append(t)
+            self.addr_eval0.append(a)
+        assert self.time_eval0[-1] == self.addr_eval0[-1]          # same multiset: the permutation check will hold
+
+    def class_of(self, idx):
+        """(kind, first, last) - the proving-key class a subcircuit needs (5 classes, tree_hash_circuit.rs:192-216)."""
+        return self.kind[idx], idx == 0, idx == self.n - 1
+
+    def make_class(self, idx):
+        kind, first, last = self.class_of(idx)
+        return ShaMerkleSubcircuit(self.curve, kind, self.ns, self.np_, first=first, last=last)
+
+    def inputs(self, idx):
+        w = dict(entry_chal=self.entry_chal, tr_chal=self.tr_chal, root=self.root, time=self.time[idx], addr=self.addr[idx],
+                 time_eval0=self.time_eval0[idx], addr_eval0=self.addr_eval0[idx])
+        if self.kind[idx] == "leaf":
+            w["leaf"] = self.leaves[idx]
+        elif self.kind[idx] == "padding":
+            w["leaf"] = bytes(64)
+        return w

@@ -378,10 +378,29 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
         return FrCodec(self.curve).enc(z[self.N_INST:self.N_INST + self.n0])
 
 
+# real SHA-256 subcircuits (sha_circuit.py): name -> (n_subcircuits, sha iterations, portals per subcircuit)
+SHA_CONFIGS = {"big-merkle-sha-8x1": (8, 1, 4), "big-merkle-sha-64x32": (64, 32, 4)}
+for _k, (_n, _ns, _np) in SHA_CONFIGS.items():
+    FAMILIES[_k] = ("big-merkle", _n)
+
+
+def make_sha_config(curve, name, class_rep, n_total=None):
+    """The class of subcircuit `class_rep` of a real-SHA big-merkle job: first leaf, leaf, parent, root, padding
+    (tree_hash_circuit.rs:192-216 order: leaves, parents level by level, root at n - 2, padding at n - 1)."""
+    from .sha_circuit import ShaMerkleSubcircuit
+    n, ns, n_portals = SHA_CONFIGS[name]
+    n = n_total or n
+    rep = 1 if class_rep is None else class_rep
+    kind = "leaf" if rep < n // 2 else ("padding" if rep == n - 1 else ("root" if rep == n - 2 else "parent"))
+    return ShaMerkleSubcircuit(curve, kind, ns, n_portals, first=(rep == 0), last=(rep == n - 1))
+
+
 def make_config(curve, name, class_rep=None):
     """The synthetic subcircuit class of a BASELINE config.  `class_rep` (a representative subcircuit index from
     `unique_subcircuits`) selects which of the config's proving-key classes: same size, different matrices
     (class seed = base seed + representative index); None = the first class."""
+    if name in SHA_CONFIGS:
+        return make_sha_config(curve, name, class_rep)
     c = CONFIGS[name]
     seed = 0x48454B41544F4E31 + (0 if class_rep is None else int(class_rep))
     return SyntheticSubcircuit(curve, c["n_c"], c["n_free"], c["n0"], class_seed=seed)

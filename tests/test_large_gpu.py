@@ -207,3 +207,39 @@ def test_config1_bls12_381_full_size_properties(ctx_bls):
     """BASELINE configs[1] shape (m = 2^21) on BLS12-381: proof valid under the trapdoor, quotient polynomial
     bit-exact vs the CPU oracle."""
     _run_config(ctx_bls, "bls12_381", "big-merkle-64x32", check_oracle_prove=False)
+
+
+@pytest.mark.parametrize("kind", ["leaf", "parent", "root", "padding"])
+def test_real_sha256_subcircuits_prove_and_verify(kind, ctx_bn254):
+    """subcircuits of the re-implemented big-merkle gadget set (hekaton_system_amd/sha_circuit.py:
+    real SHA-256 chains, digest <-> field packing, ROM running evaluations; 2 iterations, m = 2^16 / 2^17): the assignment comes
+    from the trace generator, commit + prove on the GPU, and the proof passes the trapdoor form of the verifier
+    equation with h recomputed by hk_witness_map; the statement proved is a hashlib-checked SHA-256 chain."""
+    from hekaton_system_amd.cp_groth16 import trapdoor_verify
+    from hekaton_system_amd.sha_circuit import ShaMerkleSubcircuit, example_witness, iterated_sha256, INNER_HASH_SIZE
+    cname = "bn254"
+    fc = FrCodec(cname)
+    circ = ShaMerkleSubcircuit(cname, kind, ns=2, n_portals=4, first=False, last=(kind == "padding"))
+    pk, td = generate_parameters(circ, cname, SeededRng(b"SHA-MERKLE-CLASS" * 2), ctx_bn254)
+    dpk = pk.upload(ctx_bn254)
+    w = example_witness(circ, seed=11)
+    _bits, _full, digests = circ.witness_batch([w])
+    data = w["leaf"] if kind in ("leaf", "padding") else b"".join(int(w["time"][k][1]).to_bytes(INNER_HASH_SIZE, "little") for k in range(2))
+    assert digests[0] == iterated_sha256(data, 2)
+    z_ints = circ.assignment_ints(w)[0]
+    zb = circ.assignment_bytes(w)[0]
+    kappa, r_, s_ = 0xabcdef, 0x1357_9bdf_2468, 0x2222_1111
+    w0 = fc.enc(z_ints[circ.N_INST:circ.N_INST + circ.n0])
+    com = dpk.commit(0, w0, fc.enc1(kappa))
+    a, b, c = dpk.prove(zb, fc.enc1(r_), fc.enc1(s_), fc.enc([kappa]), n_v=circ.n_v)
+    A, B, C = pk.matrices
+    h_b, m = ctx_bn254.witness_map(A, B, C, circ.N_INST, circ.n_c, zb, n_v=circ.n_v)
+    h = fc.dec(h_b)
+    assert h[-1] == 0 and m >= circ.n_c + circ.N_INST and m & (m - 1) == 0
+    trapdoor_verify(ctx_bn254, cname, td, circ.N_INST, td.stage_ranges, z_ints, h, [com], [kappa], r_, s_, (a, b, c))
+    # a wrong digest bit is not provable: the quotient is no longer a polynomial
+    bad = list(z_ints)
+    bad[-5] = 1 - bad[-5] if bad[-5] in (0, 1) else bad[-5] + 1
+    hb, _ = ctx_bn254.witness_map(A, B, C, circ.N_INST, circ.n_c, fc.enc(bad), n_v=circ.n_v)
+    assert fc.dec(hb)[-1] != 0
+    dpk.free()

@@ -64,3 +64,39 @@ def test_montgomery_bytes_match_the_ints():
     assert fc.dec(zb[:40 * 32]) == z[:40]
     assert fc.dec(zb[-8 * 32:]) == z[-8:]
     assert hashlib.sha256(b"abc").hexdigest().startswith("ba7816bf")
+
+
+def test_whole_job_witness_generation():
+    """An 8-subcircuit job (4 leaves): the tree hashes are hashlib's, the root subcircuit's digest packs to the public
+    root, every subcircuit's generated assignment satisfies ITS class's R1CS with the evals threading through, and the
+    final permutation check (time eval == addr eval) holds at the padding subcircuit."""
+    import os
+    from hekaton_system_amd.sha_circuit import ShaMerkleJob
+    leaves = [bytes([17 * i + k & 0xff for k in range(64)]) for i in range(4)]
+    job = ShaMerkleJob("bn254", 8, 1, 4, leaves, entry_chal=0xabc, tr_chal=0xdef123)
+    # plain Merkle root over truncated digests
+    h = [hashlib.sha256(l).digest() for l in leaves]
+    l1 = [hashlib.sha256(h[0][:27] + h[1][:27]).digest(), hashlib.sha256(h[2][:27] + h[3][:27]).digest()]
+    root = hashlib.sha256(l1[0][:27] + l1[1][:27]).digest()
+    assert job.digest[6] == root and job.root == int.from_bytes(root[:27], "little")
+    assert [job.class_of(i)[0] for i in range(8)] == ["leaf"] * 4 + ["parent", "parent", "root", "padding"]
+    classes = {}
+    for idx in range(8):
+        key = job.class_of(idx)
+        classes.setdefault(key, (job.make_class(idx), []))[1].append(idx)
+    assert len(classes) == 5                       # first leaf, leaf, parent, root, padding
+    for (kind, first, last), (circ, members) in classes.items():
+        circ.csr(circ.fc)
+        zs = circ.assignment_ints([job.inputs(i) for i in members])
+        _b, _f, digests = circ.witness_batch([job.inputs(i) for i in members])
+        for i, z, d in zip(members, zs, digests):
+            assert d == job.digest[i]
+            assert _check_r1cs(circ, z) == [], (kind, i)
+    # a job with one leaf changed has a different root, and the old root is then unprovable in the root subcircuit
+    job2 = ShaMerkleJob("bn254", 8, 1, 4, [leaves[0], leaves[1], leaves[2], bytes(64)], entry_chal=0xabc, tr_chal=0xdef123)
+    assert job2.root != job.root
+    circ = job2.make_class(6)
+    circ.csr(circ.fc)
+    w = job2.inputs(6)
+    w["root"] = job.root
+    assert _check_r1cs(circ, circ.assignment_ints(w)[0]) != []
