@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the BLS12-381 secondary measurement (N = 1 only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing checks of the timed proofs")
+    ap.add_argument("--witness-gen", action="store_true",
+                    help="real-SHA configs only: generate every subcircuit's witness inside the step, on the GPU, from the "
+                         "subcircuit's inputs (hk_wprog_run: the class's word program + column map, csrc/witness.cuh); the "
+                         "reference's timed region includes its synthesis (prover.rs:70-75)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand every assignment over from host memory (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--backend", default="auto",
@@ -180,7 +184,7 @@ def prepare_job_host(args, curve, rank, world, single_class=False, witnesses=Non
         members = [i for i in shard if class_of[i] == rep]
         k = min(nw, len(members))
         seed = hashlib.sha256(b"HEKATON1 class %d" % rep).digest()
-        jobs.append((curve, args.config, rep, seed, [1000 * rep + j + 1 for j in range(k)]))
+        jobs.append((curve, args.config, rep, seed, [1000 * rep + j + 1 for j in range(k)], n_total))
     t0 = time.time()
     out = {rep: (hs, assigns) for rep, hs, assigns in prepare_classes_host(jobs)}
     log("rank %d: %s host setup of %d proving-key class(es) %s in %.1f s" % (rank, curve, len(need), need, time.time() - t0))
@@ -208,7 +212,7 @@ class Job:
         t0 = time.time()
         for rep in need:
             hs, assigns = prepared["classes"][rep]
-            circ = make_config(curve, args.config, rep)
+            circ = make_config(curve, args.config, rep, self.n_total)
             keep = keep_host_class is not None and rep == keep_host_class
             pk, td = setup_device(hs, self.ctx, keep_on_device=not keep)
             dpk = pk.upload(self.ctx)
@@ -228,8 +232,13 @@ class Job:
                 zs.append(zb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, zb))
                 w0s.append(wb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, wb))
                 seeds.append(ws)
+            zgen, wprog = [], None
+            if args.witness_gen:
+                zgen = [capi.DeviceBuffer(self.ctx, circ.n_v * self.ctx.fr_bytes) for _ in range(len(members))]
+                ops, refs, vmap = circ.tape.word_program(circ.n_v)
+                wprog = self.ctx.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
             self.classes[rep] = dict(circ=circ, pk=pk, td=td, dpk=dpk, host=host, zs=zs, w0s=w0s, seeds=seeds,
-                                     members=members, matrices=pk.matrices)
+                                     members=members, matrices=pk.matrices, zgen=zgen, wprog=wprog)
             log("rank %d: %s class %d (%d subcircuits of this shard): key + %d assignments resident, %.1f s" % (
                 rank, curve, rep, len(members), len(zs), time.time() - t0))
         prepared["classes"] = None                   # the host copies are no longer needed
@@ -275,7 +284,16 @@ class Job:
         c = self.classes[self.class_of[i]]
         k = self.assign_of[i]
         rnd = self.rand[i]
-        a, b, cc = c["dpk"].prove(c["zs"][k], rnd["r_b"], rnd["s_b"], rnd["kappa_b"], n_v=c["circ"].n_v)
+        z = c["zs"][k]
+        if self.args.witness_gen:
+            # witness generation inside the step: the subcircuit's inputs (a leaf / two child hashes) and its ~40
+            # full-width values go to the device; the class's word program produces the assignment in HBM
+            from hekaton_system_amd.sha_circuit import example_witness, full_values, program_inputs
+            circ = c["circ"]
+            w = example_witness(circ, seed=c["seeds"][k], entry_chal=0x1234567, tr_chal=0x7654321)
+            cols, vals = full_values(circ, [w])
+            z = c["wprog"].run(program_inputs(circ, [w]), cols, vals, out=c["zgen"][c["members"].index(i)])
+        a, b, cc = c["dpk"].prove(z, rnd["r_b"], rnd["s_b"], rnd["kappa_b"], n_v=c["circ"].n_v)
         t = self.ctx.last_timings()
         return Stage1Response(i, Proof(a, b, cc, [com])).to_record(), t
 
@@ -328,7 +346,7 @@ class Job:
         c = self.classes[self.class_of[i]]
         circ, td = c["circ"], c["td"]
         circ.set_witness_seed(c["seeds"][self.assign_of[i]])
-        z_ints = circ.assignment_ints()
+        z_ints = circ.assignment_ints_current() if hasattr(circ, "assignment_ints_current") else circ.assignment_ints()
         A, B, C = c["matrices"]
         h_b, m = self.ctx.witness_map(A, B, C, circ.N_INST, circ.n_c, c["zs"][self.assign_of[i]], n_v=circ.n_v)
         h = self.fc.dec(h_b)
@@ -345,10 +363,12 @@ class Job:
     def close(self):
         self.pool.shutdown()
         for c in self.classes.values():
-            for b in c["zs"] + c["w0s"]:
+            for b in c["zs"] + c["w0s"] + c.get("zgen", []):
                 if isinstance(b, self.capi.DeviceBuffer):
                     b.free()
             c["dpk"].free()
+            if c.get("wprog"):
+                c["wprog"].free()
         self.ctx.close()
 
 

@@ -60,7 +60,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run"]
 
 _lib = None
 
@@ -107,6 +107,12 @@ def load():
         lib.hk_ctx_gt_bytes.argtypes = [vp, C.POINTER(sz)]
         for f in (lib.hk_points_lincomb_g1, lib.hk_points_lincomb_g2):
             f.argtypes = [vp, C.POINTER(vp), vp, sz, sz, vp]
+    if hasattr(lib, "hk_assignment_from_bits"):
+        lib.hk_assignment_from_bits.argtypes = [vp, vp, sz, vp, vp, sz, vp]
+        lib.hk_wprog_upload.argtypes = [vp, vp, sz, vp, sz, vp, sz, sz, sz, C.POINTER(vp)]
+        lib.hk_wprog_free.argtypes = [vp]
+        lib.hk_wprog_free.restype = None
+        lib.hk_wprog_run.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -282,6 +288,31 @@ class Context:
         check(fn(self.handle, vp_, coeffs.ctypes.data, len(keep), n, out.ctypes.data), fn.__name__)
         return out
 
+    def assignment_from_bits(self, bits, full_cols, full_vals, out=None):
+        """hk_assignment_from_bits: the Montgomery assignment of a bit-valued witness, materialised in HBM.  bits: uint8
+        array (one per variable); full_cols: column indices of the full-width values; full_vals: their Montgomery bytes.
+        Returns a DeviceBuffer of n_v Fr (or fills `out`)."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        cols = np.ascontiguousarray(full_cols, dtype=np.uint32)
+        vals = np.ascontiguousarray(full_vals, dtype=np.uint8)
+        n_v = bits.size
+        buf = out if out is not None else DeviceBuffer(self, n_v * self.fr_bytes)
+        check(self.lib.hk_assignment_from_bits(self.handle, bits.ctypes.data, n_v, cols.ctypes.data if cols.size else None,
+                                               vals.ctypes.data if cols.size else None, cols.size, buf.ptr),
+              "hk_assignment_from_bits")
+        return buf
+
+    def wprog_upload(self, ops, refs, vmap, n_values, n_inputs):
+        """hk_wprog_upload: a class's word program (sha_circuit.Tape.word_program) resident on the device."""
+        ops = np.ascontiguousarray(ops, dtype=np.uint32)
+        refs = np.ascontiguousarray(refs, dtype=np.uint32)
+        vmap = np.ascontiguousarray(vmap, dtype=np.uint32)
+        h = C.c_void_p()
+        check(self.lib.hk_wprog_upload(self.handle, ops.ctypes.data, ops.shape[0], refs.ctypes.data if refs.size else None,
+                                       refs.size, vmap.ctypes.data, vmap.size, int(n_values), int(n_inputs), C.byref(h)),
+              "hk_wprog_upload")
+        return WordProgram(self, h, vmap.size, int(n_inputs))
+
     def bases_upload(self, group, bases, n=None):
         """Makes a static base set resident with its shift tables (hk_bases_upload); returns a ResidentBases."""
         pb = self.g1_bytes if group == 1 else self.g2_bytes
@@ -369,6 +400,31 @@ class Context:
         h = C.c_void_p()
         check(self.lib.hk_pk_upload(self.handle, C.byref(d), C.byref(h)), "hk_pk_upload")
         return DevicePk(self, h)
+
+
+class WordProgram:
+    """hk_wprog: witness generation on the device for one proving-key class."""
+
+    def __init__(self, ctx, handle, n_v, n_inputs):
+        self.ctx, self.handle, self.n_v, self.n_inputs = ctx, handle, n_v, n_inputs
+
+    def run(self, inputs, full_cols, full_vals, out=None):
+        """inputs: uint32 (batch, n_inputs); full_cols: uint32 (k); full_vals: Montgomery bytes (batch, k * fr_bytes).
+        Returns a DeviceBuffer holding batch x n_v Fr (or fills `out`)."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint32)
+        batch = inputs.shape[0]
+        cols = np.ascontiguousarray(full_cols, dtype=np.uint32)
+        vals = np.ascontiguousarray(full_vals, dtype=np.uint8)
+        buf = out if out is not None else DeviceBuffer(self.ctx, batch * self.n_v * self.ctx.fr_bytes)
+        check(self.ctx.lib.hk_wprog_run(self.ctx.handle, self.handle, inputs.ctypes.data, batch,
+                                        cols.ctypes.data if cols.size else None, vals.ctypes.data if cols.size else None,
+                                        cols.size, buf.ptr), "hk_wprog_run")
+        return buf
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.hk_wprog_free(self.handle)
+            self.handle = None
 
 
 class ResidentBases:

@@ -112,13 +112,18 @@ struct Ops {
     static hk_status msm_bases(hk_ctx*, const hk_bases*, const void*, size_t, int, int, void*);
     static hk_status pairing_products(hk_ctx*, const void* const*, size_t, const void* const*, size_t, size_t, void*);
     static hk_status points_lincomb(hk_ctx*, int, const void* const*, const void*, size_t, size_t, void*);
+    static hk_status assignment_from_bits(hk_ctx*, const void*, size_t, const uint32_t*, const void*, size_t, void*);
+    static hk_status wprog_upload(hk_ctx*, const uint32_t*, size_t, const uint32_t*, size_t, const uint32_t*, size_t, size_t,
+                                  size_t, hk_wprog**);
+    static void wprog_free(hk_wprog*);
+    static hk_status wprog_run(hk_ctx*, const hk_wprog*, const uint32_t*, size_t, const uint32_t*, const void*, size_t, void*);
 
     static const CurveOps* table() {
         static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
-                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb};
+                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run};
         return &t;
     }
 };

@@ -247,6 +247,24 @@ hk_status hk_msm_bases(hk_ctx* ctx, const hk_bases* b, const void* scalars, size
     if (!ctx || !b || !out || b->ctx != ctx) return HK_ERR_ARG;
     return ctx->ops->msm_bases(ctx, b, scalars, n_scalars, mont, checked, out);
 }
+hk_status hk_wprog_upload(hk_ctx* ctx, const uint32_t* ops, size_t n_ops, const uint32_t* refs, size_t n_refs,
+                          const uint32_t* map, size_t n_v, size_t n_values, size_t n_inputs, hk_wprog** out) {
+    if (!ctx || !ops || !map || !out || (n_refs && !refs)) return HK_ERR_ARG;
+    return ctx->ops->wprog_upload(ctx, ops, n_ops, refs, n_refs, map, n_v, n_values, n_inputs, out);
+}
+void hk_wprog_free(hk_wprog* w) {
+    if (w) w->ops->wprog_free(w);
+}
+hk_status hk_wprog_run(hk_ctx* ctx, const hk_wprog* w, const uint32_t* inputs, size_t batch, const uint32_t* full_cols,
+                       const void* full_vals_mont, size_t n_full, void* z_out) {
+    if (!ctx || !w || w->ctx != ctx || !z_out || (batch && !inputs) || (n_full && (!full_cols || !full_vals_mont))) return HK_ERR_ARG;
+    return ctx->ops->wprog_run(ctx, w, inputs, batch, full_cols, full_vals_mont, n_full, z_out);
+}
+hk_status hk_assignment_from_bits(hk_ctx* ctx, const void* bits, size_t n_v, const uint32_t* full_cols,
+                                  const void* full_vals_mont, size_t n_full, void* z_out) {
+    if (!ctx || !z_out || (n_v && !bits) || (n_full && (!full_cols || !full_vals_mont))) return HK_ERR_ARG;
+    return ctx->ops->assignment_from_bits(ctx, bits, n_v, full_cols, full_vals_mont, n_full, z_out);
+}
 hk_status hk_points_lincomb_g1(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out) {
     if (!ctx || !vecs || !coeffs_mont || (n && !out)) return HK_ERR_ARG;
     return ctx->ops->points_lincomb(ctx, 1, vecs, coeffs_mont, k, n, out);

@@ -114,6 +114,13 @@ struct CurveOps {
     size_t gt_bytes;
     hk_status (*points_lincomb)(hk_ctx*, int group, const void* const* vecs, const void* coeffs, size_t k, size_t n,
                                 void* out);
+    hk_status (*assignment_from_bits)(hk_ctx*, const void* bits, size_t n_v, const uint32_t* full_cols,
+                                      const void* full_vals, size_t n_full, void* z_out);
+    hk_status (*wprog_upload)(hk_ctx*, const uint32_t* ops, size_t n_ops, const uint32_t* refs, size_t n_refs,
+                              const uint32_t* map, size_t n_v, size_t n_values, size_t n_inputs, hk_wprog** out);
+    void (*wprog_free)(hk_wprog*);
+    hk_status (*wprog_run)(hk_ctx*, const hk_wprog*, const uint32_t* inputs, size_t batch, const uint32_t* full_cols,
+                           const void* full_vals, size_t n_full, void* z_out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();
@@ -143,6 +150,19 @@ struct hk_bases {
     const hk::CurveOps* ops;
     hk_ctx* ctx;
     void* impl;
+};
+
+namespace hk {
+struct WprogImpl {                 // a class's word program on the device (witness.cuh)
+    uint32_t *ops = nullptr, *refs = nullptr, *map = nullptr;
+    uint32_t n_ops = 0, n_refs = 0, n_values = 0, n_inputs = 0;
+    size_t n_v = 0;
+};
+}  // namespace hk
+struct hk_wprog {
+    const hk::CurveOps* ops;
+    hk_ctx* ctx;
+    hk::WprogImpl* impl;
 };
 
 namespace hk {

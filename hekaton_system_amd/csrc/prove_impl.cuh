@@ -15,6 +15,7 @@
 #include "curve_ops_impl.cuh"
 #include "ntt.cuh"
 #include "fixed_base.cuh"
+#include "witness.cuh"
 
 namespace hk {
 
@@ -850,6 +851,140 @@ hk_status Ops<C>::points_lincomb(hk_ctx* ctx, int group, const void* const* vecs
         return HK_OK;
     };
     return group == 1 ? run(Fq()) : run(Fq2());
+}
+
+// z[i] = bits[i] ? 1 : 0 (Montgomery), then z[full_cols[k]] = full_vals[k]
+template <class Fr>
+__global__ void k_expand_bits(const unsigned char* __restrict__ bits, size_t n, Fr* __restrict__ z) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(&z[i], bits[i] ? Fr::one() : Fr::zero());
+}
+template <class Fr>
+__global__ void k_scatter_full(const u32* __restrict__ cols, const Fr* __restrict__ vals, u32 k, size_t n, Fr* __restrict__ z) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    u32 c = cols[j];
+    if (c < n) fr_store(&z[c], fr_load(&vals[j]));
+}
+
+template <class C>
+hk_status Ops<C>::assignment_from_bits(hk_ctx* ctx, const void* bits, size_t n_v, const uint32_t* full_cols,
+                                       const void* full_vals, size_t n_full, void* z_out) {
+    if (n_v == 0) return HK_OK;
+    if (!is_device_ptr(z_out)) return HK_ERR_ARG;
+    for (size_t k = 0; k < n_full; k++) if (!is_device_ptr(full_cols) && full_cols[k] >= n_v) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    HK_TRY(L->reserve(al256(n_v) + al256(4 * n_full) + al256(sizeof(Fr) * n_full) + 4096));
+    const void *bd, *cd = nullptr, *vd = nullptr;
+    HK_TRY(to_device(L, bits, n_v, &bd));
+    if (n_full) {
+        HK_TRY(to_device(L, full_cols, 4 * n_full, &cd));
+        HK_TRY(to_device(L, full_vals, sizeof(Fr) * n_full, &vd));
+    }
+    hipLaunchKernelGGL((k_expand_bits<Fr>), dim3((u32)((n_v + 255) / 256)), dim3(256), 0, L->stream, (const unsigned char*)bd, n_v,
+                       (Fr*)z_out);
+    if (n_full)
+        hipLaunchKernelGGL((k_scatter_full<Fr>), dim3((u32)((n_full + 63) / 64)), dim3(64), 0, L->stream, (const u32*)cd,
+                           (const Fr*)vd, (u32)n_full, n_v, (Fr*)z_out);
+    HK_HIP(hipGetLastError());
+    HK_HIP(hipStreamSynchronize(L->stream));
+    return HK_OK;
+}
+
+// ---- word programs (witness.cuh) ---------------------------------------------------------------------------------
+template <class C>
+hk_status Ops<C>::wprog_upload(hk_ctx* ctx, const uint32_t* ops, size_t n_ops, const uint32_t* refs, size_t n_refs,
+                               const uint32_t* map, size_t n_v, size_t n_values, size_t n_inputs, hk_wprog** out) {
+    *out = nullptr;
+    if (n_values >= (1u << 20) || n_ops == 0 || n_v == 0 || n_v >= ((size_t)1 << 32)) return HK_ERR_ARG;
+    // validate on the host what the interpreter will index with: operand references, operand tables, the column map
+    size_t vid = 0;
+    auto ref_ok = [&](uint32_t r) { return (r & 0xfffffu) < vid; };
+    for (size_t k = 0; k < n_ops; k++) {
+        const uint32_t* o = ops + 8 * k;
+        bool ok = true;
+        switch (o[0]) {
+            case WOP_INPUT: ok = o[4] < n_inputs; break;
+            case WOP_CONST: break;
+            case WOP_XOR: case WOP_AND: ok = ref_ok(o[1]) && ref_ok(o[2]); break;
+            case WOP_CH: case WOP_MAJ: ok = ref_ok(o[1]) && ref_ok(o[2]) && ref_ok(o[3]); break;
+            case WOP_ADD:
+                ok = (size_t)o[1] + o[2] <= n_refs && o[2] <= 16;
+                for (uint32_t j = 0; ok && j < o[2]; j++) ok = ref_ok(refs[o[1] + j]);
+                vid++;
+                break;
+            case WOP_PACK4:
+                ok = (size_t)o[1] + 4 <= n_refs;
+                for (uint32_t j = 0; ok && j < 4; j++) ok = ref_ok(refs[o[1] + j]);
+                break;
+            default: ok = false;
+        }
+        if (!ok) return HK_ERR_ARG;
+        vid++;
+    }
+    if (vid != n_values) return HK_ERR_ARG;
+    for (size_t i = 0; i < n_v; i++)
+        if (map[i] != 0xffffffffu && (map[i] >> 5) >= n_values) return HK_ERR_ARG;
+    HK_HIP(hipSetDevice(ctx->device));
+    WprogImpl* w = new WprogImpl();
+    hk_wprog* h = new hk_wprog{ctx->ops, ctx, w};
+    auto fail = [&](hk_status st) { Ops<C>::wprog_free(h); return st; };
+    auto up = [&](u32** dst, const uint32_t* src, size_t n) -> bool {
+        if (hipMalloc((void**)dst, 4 * (n ? n : 1)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return n == 0 || hipMemcpy(*dst, src, 4 * n, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(&w->ops, ops, 8 * n_ops) || !up(&w->refs, refs, n_refs) || !up(&w->map, map, n_v)) return fail(HK_ERR_NOMEM);
+    w->n_ops = (u32)n_ops; w->n_refs = (u32)n_refs; w->n_values = (u32)n_values; w->n_inputs = (u32)n_inputs; w->n_v = n_v;
+    *out = h;
+    return HK_OK;
+}
+
+template <class C>
+void Ops<C>::wprog_free(hk_wprog* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (u32* p : {h->impl->ops, h->impl->refs, h->impl->map}) if (p) (void)hipFree(p);
+    delete h->impl;
+    delete h;
+}
+
+template <class C>
+hk_status Ops<C>::wprog_run(hk_ctx* ctx, const hk_wprog* h, const uint32_t* inputs, size_t batch,
+                            const uint32_t* full_cols, const void* full_vals, size_t n_full, void* z_out) {
+    const WprogImpl* w = h->impl;
+    if (batch == 0) return HK_OK;
+    if (batch >= (1u << 16) || !is_device_ptr(z_out)) return HK_ERR_ARG;
+    if (!is_device_ptr(full_cols))
+        for (size_t k = 0; k < n_full; k++) if (full_cols[k] >= w->n_v) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    size_t need = al256(4 * batch * w->n_inputs) + al256(4 * (size_t)w->n_values * batch) + al256(4 * n_full) +
+                  al256(sizeof(Fr) * n_full * batch) + 8192;
+    HK_TRY(L->reserve(need));
+    hipStream_t s = L->stream;
+    const void *in_d, *cd = nullptr, *vd = nullptr;
+    HK_TRY(to_device(L, inputs, 4 * batch * w->n_inputs, &in_d));
+    if (n_full) {
+        HK_TRY(to_device(L, full_cols, 4 * n_full, &cd));
+        HK_TRY(to_device(L, full_vals, sizeof(Fr) * n_full * batch, &vd));
+    }
+    u32* values = L->alloc_n<u32>((size_t)w->n_values * batch);
+    if (!values) return HK_ERR_NOMEM;
+    hipLaunchKernelGGL((k_word_program<0>), dim3((u32)((batch + 63) / 64)), dim3(64), 0, s, w->ops, w->n_ops, w->refs,
+                       (const u32*)in_d, w->n_inputs, (u32)batch, values);
+    hipLaunchKernelGGL((k_witness_expand<Fr>), dim3((u32)((w->n_v + 255) / 256), (u32)batch), dim3(256), 0, s, w->map, w->n_v,
+                       (const u32*)values, (u32)batch, (Fr*)z_out);
+    if (n_full)
+        hipLaunchKernelGGL((k_scatter_full_batch<Fr>), dim3((u32)((n_full + 63) / 64), (u32)batch), dim3(64), 0, s,
+                           (const u32*)cd, (const Fr*)vd, (u32)n_full, w->n_v, (Fr*)z_out);
+    HK_HIP(hipGetLastError());
+    HK_HIP(hipStreamSynchronize(s));
+    return HK_OK;
 }
 
 // ---- multi-pairings (pairing.cuh) ------------------------------------------------------------------------------

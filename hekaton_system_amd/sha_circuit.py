@@ -48,20 +48,31 @@ ONE = 0                       # column of the constant 1
 
 class Word:
     """32 bit positions, least significant first: `cols[i]` = R1CS column of bit i, or -1 for the constant 0
-    (shifts).  `val`: the word's value over the batch (EVAL mode), else None.  `const`: a Python int for constants."""
-    __slots__ = ("cols", "val")
+    (shifts).  `val`: the word's value over the batch (EVAL mode), else None.  (`vid`, `rot`, `shr`): the word as a view
+    of value `vid` of the WORD PROGRAM the tape records (rotated right by `rot`, or shifted right by `shr`)."""
+    __slots__ = ("cols", "val", "vid", "rot", "shr")
 
-    def __init__(self, cols, val):
-        self.cols, self.val = cols, val
+    def __init__(self, cols, val, vid, rot=0, shr=0):
+        self.cols, self.val, self.vid, self.rot, self.shr = cols, val, vid, rot, shr
+
+    def ref(self):
+        return self.vid | (self.rot << 20) | (self.shr << 25)
 
 
 def _rotr(w, k):
-    return Word(np.roll(w.cols, -k), None if w.val is None else ((w.val >> np.uint32(k)) | (w.val << np.uint32(32 - k))))
+    assert w.shr == 0
+    return Word(np.roll(w.cols, -k), None if w.val is None else ((w.val >> np.uint32(k)) | (w.val << np.uint32(32 - k))),
+                w.vid, (w.rot + k) % 32, 0)
 
 
 def _shr(w, k):
+    assert w.rot == 0 and w.shr == 0
     cols = np.concatenate([w.cols[k:], np.full(k, -1, np.int64)])
-    return Word(cols, None if w.val is None else (w.val >> np.uint32(k)))
+    return Word(cols, None if w.val is None else (w.val >> np.uint32(k)), w.vid, 0, k)
+
+
+# word-program opcodes (interpreted by k_word_program on the GPU and by `run_word_program` on the host)
+OP_INPUT, OP_CONST, OP_XOR, OP_CH, OP_AND, OP_MAJ, OP_ADD, OP_PACK4 = range(8)
 
 
 class Tape:
@@ -78,6 +89,24 @@ class Tape:
         self.consts = {}                        # pinned constant words by value (allocated at first use, both modes)
         self.bit_records = []                   # EVAL: (first column, bit positions, word values)
         self.full_records = []                  # EVAL: (column, [python int per batch element])
+        # the word program (recorded identically in both modes): one entry per VALUE
+        self.prog = []                          # (opcode, a, b, c, imm)
+        self.refs = []                          # operand references of ADD / PACK4 entries
+        self.n_values = 0
+        self.n_inputs = 0
+        self.alloc_map = []                     # (first column, bit positions, value id)
+
+    def _value(self, op, a=0, b=0, c=0, imm=0, count=1):
+        vid = self.n_values
+        self.prog.append((op, a, b, c, imm))
+        self.n_values += count
+        return vid
+
+    def input_value(self):
+        """The next 32-bit input of the subcircuit (a leaf word, a byte of a child hash) as a program value."""
+        k = self.n_inputs
+        self.n_inputs += 1
+        return self._value(OP_INPUT, imm=k)
 
     # ---- allocation -----------------------------------------------------------------------------------
     def _alloc(self, k):
@@ -93,12 +122,14 @@ class Tape:
     def _emit(self, m, rows, cols, coefs):
         self.trip[m].append((np.asarray(rows, np.int64), np.asarray(cols, np.int64), np.asarray(coefs, np.int64)))
 
-    def alloc_bits(self, pos, val, boolean):
-        """New witness bits for the bit positions `pos` of the word value `val`; booleanity rows b * (1 - b) = 0 when
-        the bits are not boolean by construction.  Returns their columns."""
+    def alloc_bits(self, pos, val, boolean, vid):
+        """New witness bits for the bit positions `pos` of the word value `val` (= program value `vid`); booleanity
+        rows b * (1 - b) = 0 when the bits are not boolean by construction.  Returns their columns."""
         k = len(pos)
         first = self._alloc(k)
         cols = np.arange(first, first + k, dtype=np.int64)
+        if k:
+            self.alloc_map.append((first, np.asarray(pos, np.uint32), vid))
         if self.build:
             if boolean:
                 r = self._rows(k)
@@ -109,8 +140,11 @@ class Tape:
             self.bit_records.append((first, np.asarray(pos, np.uint32), val))
         return cols
 
-    def alloc_word(self, val, boolean=True):
-        return Word(self.alloc_bits(np.arange(32), val, boolean), val)
+    def alloc_word(self, val, boolean, vid):
+        return Word(self.alloc_bits(np.arange(32), val, boolean, vid), val, vid)
+
+    def input_word(self, val):
+        return self.alloc_word(val, True, self.input_value())
 
     def alloc_full(self, vals):
         """One full-width witness; vals: list of Python ints (EVAL) or None."""
@@ -125,7 +159,8 @@ class Tape:
         both = (x.cols >= 0) & (y.cols >= 0)
         val = None if self.build else x.val ^ y.val
         pos = np.nonzero(both)[0]
-        new = self.alloc_bits(pos, val, boolean=False)
+        vid = self._value(OP_XOR, x.ref(), y.ref())
+        new = self.alloc_bits(pos, val, False, vid)
         cols = np.where(x.cols >= 0, x.cols, y.cols).copy()
         cols[pos] = new
         if self.build and len(pos):
@@ -136,7 +171,7 @@ class Tape:
             self._emit("B", r, ya, np.ones(k, np.int64))
             self._emit("C", np.concatenate([r, r, r]), np.concatenate([xa, ya, new]),
                        np.concatenate([np.ones(k, np.int64), np.ones(k, np.int64), -np.ones(k, np.int64)]))
-        return Word(cols, val)
+        return Word(cols, val, vid)
 
     def xor3(self, x, y, z):
         return self.xor(self.xor(x, y), z)
@@ -144,7 +179,7 @@ class Tape:
     def ch(self, e, f, g):
         """(e & f) ^ (~e & g):  e * (f - g) = ch - g."""
         val = None if self.build else (e.val & f.val) ^ (~e.val & g.val)
-        w = self.alloc_word(val, boolean=False)
+        w = self.alloc_word(val, False, self._value(OP_CH, e.ref(), f.ref(), g.ref()))
         if self.build:
             r = self._rows(32)
             self._emit("A", r, e.cols, np.ones(32, np.int64))
@@ -157,9 +192,9 @@ class Tape:
     def maj(self, a, b, c):
         """t = a * b;  c * (a + b - 2 t) = maj - t."""
         tv = None if self.build else a.val & b.val
-        t = self.alloc_word(tv, boolean=False)
+        t = self.alloc_word(tv, False, self._value(OP_AND, a.ref(), b.ref()))
         val = None if self.build else (a.val & b.val) ^ (a.val & c.val) ^ (b.val & c.val)
-        w = self.alloc_word(val, boolean=False)
+        w = self.alloc_word(val, False, self._value(OP_MAJ, a.ref(), b.ref(), c.ref()))
         if self.build:
             o = np.ones(32, np.int64)
             r = self._rows(32)
@@ -181,8 +216,12 @@ class Tape:
             tot = np.full(self.batch, const, np.uint64)
             for w in words:
                 tot = tot + w.val.astype(np.uint64)
-        r = self.alloc_word(None if self.build else (tot & np.uint64(0xffffffff)).astype(np.uint32))
-        carry = self.alloc_bits(np.arange(cbits), None if self.build else (tot >> np.uint64(32)).astype(np.uint32), True)
+        first_ref = len(self.refs)
+        self.refs += [w.ref() for w in words]
+        vid = self._value(OP_ADD, first_ref, len(words), 0, const, count=2)          # two values: low word, carry
+        r = self.alloc_word(None if self.build else (tot & np.uint64(0xffffffff)).astype(np.uint32), True, vid)
+        carry = self.alloc_bits(np.arange(cbits), None if self.build else (tot >> np.uint64(32)).astype(np.uint32), True,
+                                vid + 1)
         if self.build:
             row = self._rows(1)[0]
             pw = (1 << np.arange(32, dtype=np.int64))
@@ -234,7 +273,7 @@ class Tape:
         if v in self.consts:
             return self.consts[v]
         val = None if self.build else np.full(self.batch, v, np.uint32)
-        w = self.alloc_word(val, boolean=False)
+        w = self.alloc_word(val, False, self._value(OP_CONST, imm=v))
         if self.build:
             r = self._rows(32)
             o = np.ones(32, np.int64)
@@ -295,6 +334,17 @@ class Tape:
             tab = fc.enc(table).reshape(len(table), fc.nb)
             out.append((row_ptr, cols.astype(np.uint32), np.ascontiguousarray(tab[vidx]).ravel(), vidx, table))
         return out
+
+    def word_program(self, n_v):
+        """The recorded program in the arrays hk_wprog_upload takes: ops uint32 (n, 8), refs uint32, map uint32 (n_v):
+        map[col] = value id << 5 | bit position for bit-valued columns, 0xffffffff otherwise (instance, full-width)."""
+        ops = np.zeros((len(self.prog), 8), np.uint32)
+        for k, (op, a, b, c, imm) in enumerate(self.prog):
+            ops[k, :5] = (op, a, b, c, imm)
+        vmap = np.full(n_v, 0xffffffff, np.uint32)
+        for first, pos, vid in self.alloc_map:
+            vmap[first:first + len(pos)] = (np.uint32(vid) << np.uint32(5)) | pos
+        return ops, np.array(self.refs, np.uint32), vmap
 
     def assignment_bits(self, n_v):
         """EVAL: (batch, n_v) uint8 with every bit variable's value (column 0 = 1; full-width columns left 0)."""
@@ -382,7 +432,7 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
         # ---- the hash chain
         if self.kind in ("leaf", "padding"):
             # 64 witnessed bytes as 16 big-endian words (bits boolean)
-            words = [t.alloc_word(inp["leaf_words"][:, k] if ev else None) for k in range(16)]
+            words = [t.input_word(inp["leaf_words"][:, k] if ev else None) for k in range(16)]
             if self.kind == "padding":
                 zero = t.const_word(0)       # EMPTY_LEAF: pin the input to zero through one pinned word
                 for w in words:
@@ -427,7 +477,7 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
         """The two children hashes (values of the first two time-ordered entries) as 54 message bytes in 14 big-endian
         words; the last word carries the 0x80 padding marker in its free bytes."""
         ev = not t.build
-        byte_cols, byte_vals = [], []
+        byte_cols, byte_vals, byte_vids = [], [], []
         for child in range(2):
             v_col = time_e[child][1]
             if ev:
@@ -436,27 +486,38 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
             terms = []
             for j in range(INNER_HASH_SIZE):
                 bv = raw[:, j].astype(np.uint32) if ev else None
-                cols = t.alloc_bits(np.arange(8), bv, True)
-                byte_cols.append(cols); byte_vals.append(bv)
+                vid = t.input_value()
+                cols = t.alloc_bits(np.arange(8), bv, True, vid)
+                byte_cols.append(cols); byte_vals.append(bv); byte_vids.append(vid)
                 terms += [(1 << (8 * j + b), int(cols[b])) for b in range(8)]
             t.big_row(terms, [(1, ONE)], [(1, v_col)])      # the unpacked bits re-pack to the `get` value
         words = []
+        zero_vid = t._value(OP_CONST, imm=0)
         for k in range(14):
             cols = np.full(32, -1, np.int64)
             val = np.zeros(t.batch, np.uint32) if ev else None
+            parts = []
             for bi in range(4):
                 j = 4 * k + bi
                 if j < 54:
                     cols[8 * (3 - bi):8 * (3 - bi) + 8] = byte_cols[j]
+                    parts.append(byte_vids[j])
                     if ev:
                         val |= byte_vals[j] << np.uint32(8 * (3 - bi))
+                else:
+                    parts.append(zero_vid)
+            marker = 0
             if k == 13:                                      # bytes 52, 53 then 0x80, 0x00: the marker bit is a pinned 1
-                one_bit = t.alloc_bits(np.arange(1), np.ones(t.batch, np.uint32) if ev else None, False)
+                one_bit = t.alloc_bits(np.arange(1), np.ones(t.batch, np.uint32) if ev else None, False,
+                                       t._value(OP_CONST, imm=1))
                 t.big_row([(1, int(one_bit[0]))], [(1, ONE)], [(1, ONE)])
                 cols[8 * 1 + 7] = one_bit[0]                 # byte 2 of the word = 0x80: its bit 7
+                marker = 0x8000
                 if ev:
                     val |= np.uint32(0x8000)
-            words.append(Word(cols, val))
+            first_ref = len(t.refs)
+            t.refs += parts
+            words.append(Word(cols, val, t._value(OP_PACK4, first_ref, 4, 0, marker)))
         return words
 
     # ---- MultiStageConstraintSynthesizer -------------------------------------------------------------------
@@ -583,6 +644,18 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
             vals = [inputs[b]["entry_chal"], inputs[b]["tr_chal"], inputs[b]["root"]] + [int(v[b]) for v in full.values()]
             out[b, cols] = fc.enc(vals).reshape(len(cols), fc.nb)
         return out.reshape(len(inputs), self.n_v * fc.nb)
+
+
+def packed_assignments(circ, inputs):
+    """For hk_assignment_from_bits: per subcircuit (bits uint8[n_v], full_cols uint32[k], full_vals Montgomery bytes)."""
+    inputs = inputs if isinstance(inputs, list) else [inputs]
+    bits, full, _ = circ.witness_batch(inputs)
+    cols = np.array([1, 2, 3] + list(full.keys()), np.uint32)
+    out = []
+    for b, w in enumerate(inputs):
+        vals = [w["entry_chal"], w["tr_chal"], w["root"]] + [int(v[b]) for v in full.values()]
+        out.append((bits[b], cols, circ.fc.enc(vals)))
+    return out
 
 
 def node_hash_field(digest):
@@ -723,3 +796,92 @@ class ShaMerkleJob:
         elif self.kind[idx] == "padding":
             w["leaf"] = bytes(64)
         return w
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The word program: what the GPU interprets (csrc/witness.cuh `k_word_program`), restated in numpy for the CPU tests.
+def _ref_val(values, ref):
+    v = values[ref & 0xfffff]
+    rot, shr = (ref >> 20) & 31, (ref >> 25) & 31
+    if shr:
+        return v >> np.uint32(shr)
+    if rot:
+        return (v >> np.uint32(rot)) | (v << np.uint32(32 - rot))
+    return v
+
+
+def run_word_program(ops, refs, n_values, inputs):
+    """inputs: uint32 (batch, n_inputs).  Returns the value table uint32 (n_values, batch)."""
+    B = inputs.shape[0]
+    values = np.zeros((n_values, B), np.uint32)
+    vid = 0
+    for op, a, b, c, imm in ops[:, :5].tolist():
+        if op == OP_INPUT:
+            values[vid] = inputs[:, imm]
+        elif op == OP_CONST:
+            values[vid] = imm
+        elif op == OP_XOR:
+            values[vid] = _ref_val(values, a) ^ _ref_val(values, b)
+        elif op == OP_CH:
+            e, f, g = _ref_val(values, a), _ref_val(values, b), _ref_val(values, c)
+            values[vid] = (e & f) ^ (~e & g)
+        elif op == OP_AND:
+            values[vid] = _ref_val(values, a) & _ref_val(values, b)
+        elif op == OP_MAJ:
+            x, y, z = _ref_val(values, a), _ref_val(values, b), _ref_val(values, c)
+            values[vid] = (x & y) ^ (x & z) ^ (y & z)
+        elif op == OP_ADD:
+            tot = np.full(B, imm, np.uint64)
+            for k in range(b):
+                tot = tot + _ref_val(values, int(refs[a + k])).astype(np.uint64)
+            values[vid] = (tot & np.uint64(0xffffffff)).astype(np.uint32)
+            values[vid + 1] = (tot >> np.uint64(32)).astype(np.uint32)
+            vid += 1
+        elif op == OP_PACK4:
+            p = [values[int(refs[a + k]) & 0xfffff] for k in range(4)]
+            values[vid] = (p[0] << np.uint32(24)) | (p[1] << np.uint32(16)) | (p[2] << np.uint32(8)) | p[3] | np.uint32(imm)
+        vid += 1
+    assert vid == n_values
+    return values
+
+
+def program_inputs(circ, inputs):
+    """The per-subcircuit uint32 inputs of the class's word program: 16 big-endian leaf words, or the 54 bytes of the
+    two children hashes."""
+    if circ.kind in ("leaf", "padding"):
+        leaves = np.frombuffer(b"".join(i["leaf"] for i in inputs), np.uint8).reshape(len(inputs), 64)
+        return (leaves.reshape(len(inputs), 16, 4).astype(np.uint32) @ np.array([1 << 24, 1 << 16, 1 << 8, 1], np.uint32)).astype(np.uint32)
+    out = np.zeros((len(inputs), 2 * INNER_HASH_SIZE), np.uint32)
+    for b, w in enumerate(inputs):
+        raw = b"".join(int(w["time"][k][1]).to_bytes(32, "little")[:INNER_HASH_SIZE] for k in range(2))
+        out[b] = np.frombuffer(raw, np.uint8)
+    return out
+
+
+def full_values(circ, inputs):
+    """(columns uint32[k], Montgomery bytes (batch, k * 32)) of the full-width variables: the three instance values,
+    the portal entries and the running-evaluation chain - ~40 field values per subcircuit, computed on the host."""
+    r = circ.r
+    ni = circ.N_INST
+    cols = [1, 2, 3]
+    rows = []
+    for w in inputs:
+        ech, tr = w["entry_chal"], w["tr_chal"]
+        vals = [ech, tr, w["root"]]
+        col = ni
+        c_local = []
+        for key in ("time", "addr"):
+            for a, v in w[key]:
+                vals += [a, v]; c_local += [col, col + 1]; col += 2
+        for key, e0 in (("time", w["time_eval0"]), ("addr", w["addr_eval0"])):
+            vals.append(e0); c_local.append(col); col += 1
+            cur = e0
+            for a, v in w[key]:
+                e = (a + ech * v) % r
+                cur = cur * ((tr - e) % r) % r
+                vals += [e, cur]; c_local += [col, col + 1]; col += 2
+        for k in range(1, circ.n_addr):
+            d = (w["addr"][k][0] - w["addr"][k - 1][0]) % r
+            vals += [pow(d, -1, r) if d else 0, 0 if d else 1]; c_local += [col, col + 1]; col += 2
+        rows.append(circ.fc.enc(vals))
+    return np.array(cols + c_local, np.uint32), np.stack(rows)

@@ -395,12 +395,12 @@ def make_sha_config(curve, name, class_rep, n_total=None):
     return ShaMerkleSubcircuit(curve, kind, ns, n_portals, first=(rep == 0), last=(rep == n - 1))
 
 
-def make_config(curve, name, class_rep=None):
+def make_config(curve, name, class_rep=None, n_total=None):
     """The synthetic subcircuit class of a BASELINE config.  `class_rep` (a representative subcircuit index from
     `unique_subcircuits`) selects which of the config's proving-key classes: same size, different matrices
     (class seed = base seed + representative index); None = the first class."""
     if name in SHA_CONFIGS:
-        return make_sha_config(curve, name, class_rep)
+        return make_sha_config(curve, name, class_rep, n_total)
     c = CONFIGS[name]
     seed = 0x48454B41544F4E31 + (0 if class_rep is None else int(class_rep))
     return SyntheticSubcircuit(curve, c["n_c"], c["n_free"], c["n0"], class_seed=seed)
@@ -419,8 +419,9 @@ def prepare_class_host(job):
     parent initialises HIP.  job = (curve, config name, class representative, setup seed bytes, [witness seeds]);
     returns (class_rep, HostSetup, [(seed, full assignment bytes, stage-0 witness bytes)])."""
     from .cp_groth16 import SeededRng, setup_host
-    curve, name, rep, seed, witness_seeds = job
-    circ = make_config(curve, name, rep)
+    curve, name, rep, seed, witness_seeds = job[:5]
+    n_total = job[5] if len(job) > 5 else None
+    circ = make_config(curve, name, rep, n_total)
     hs = setup_host(circ, curve, SeededRng(seed))
     assigns = []
     for ws in witness_seeds:

@@ -207,6 +207,34 @@ hk_status hk_msm_bases(hk_ctx* ctx, const hk_bases* b, const void* scalars, size
  * mpi-snark/src/lib.rs:68-71 `serialize_to_vec`): the wire format is canonical little-endian, the ABI Montgomery. */
 hk_status hk_field_convert(hk_ctx* ctx, int which, const void* in, void* out, size_t n, int to_mont);
 
+/* ---- witness materialisation ------------------------------------------------------------------
+ * A gadget circuit's assignment is almost entirely bits (SHA-256: > 99.99 %).  The witness generator hands over ONE
+ * BYTE per variable plus the few full-width values, and the assignment `cs.full_assignment()` would hold
+ * (cp-groth16/src/constraint_synthesizer.rs:102-106: instance || witness, 32 B Montgomery each) is materialised in
+ * HBM: z[i] = bits[i] ? 1 : 0, then z[full_cols[k]] = full_vals[k].  PCIe carries n_v bytes instead of 32 n_v.
+ * bits [h|d]: n_v bytes (0 / 1; bits[0] = 1 for the constant); full_cols [h|d]: n_full column indices;
+ * full_vals_mont [h|d]: n_full Fr; z_out [d]: n_v Fr, ready for hk_commit / hk_prove. */
+hk_status hk_assignment_from_bits(hk_ctx* ctx, const void* bits, size_t n_v, const uint32_t* full_cols,
+                                  const void* full_vals_mont, size_t n_full, void* z_out);
+
+/* Witness generation ON the device for gadget circuits: a class's WORD PROGRAM (the dataflow of its bit gadgets at
+ * 32-bit word granularity, recorded when its R1CS is built) + column map are uploaded once; hk_wprog_run then turns the
+ * inputs of `batch` subcircuits (a leaf's 16 words, the 54 bytes of two child hashes) into their full Montgomery
+ * assignments in HBM - replaces the witness side of `circuit.generate_constraints` (cp-groth16/src/prover.rs:70-75;
+ * distributed-prover/src/tree_hash_circuit.rs:313-398) for a re-implemented gadget set (csrc/witness.cuh).
+ *   ops [h]: n_ops x 8 u32 (opcode, a, b, c, imm, 0, 0, 0): 0 INPUT imm | 1 CONST imm | 2 XOR a b | 3 CH a b c | 4 AND a b |
+ *            5 MAJ a b c | 6 ADD refs[a .. a+b) + imm -> TWO values (low word, carry) | 7 PACK4 refs[a .. a+4) | imm;
+ *            an operand = value id | rotate-right << 20 | shift-right << 25; every entry defines the next value id(s)
+ *   map [h]: n_v u32, value id << 5 | bit position, or 0xffffffff for instance / full-width columns
+ *   hk_wprog_run: inputs [h|d] batch x n_inputs u32; full_cols [h|d] n_full columns; full_vals_mont [h|d] batch x n_full Fr;
+ *            z_out [d]: batch x n_v Fr.  HK_ERR_ARG for a program that would index out of range. */
+typedef struct hk_wprog hk_wprog;
+hk_status hk_wprog_upload(hk_ctx* ctx, const uint32_t* ops, size_t n_ops, const uint32_t* refs, size_t n_refs,
+                          const uint32_t* map, size_t n_v, size_t n_values, size_t n_inputs, hk_wprog** out);
+void      hk_wprog_free(hk_wprog* w);
+hk_status hk_wprog_run(hk_ctx* ctx, const hk_wprog* w, const uint32_t* inputs, size_t batch, const uint32_t* full_cols,
+                       const void* full_vals_mont, size_t n_full, void* z_out);
+
 /* ---- proving-key residency -------------------------------------------------------------- */
 hk_status hk_pk_upload(hk_ctx* ctx, const hk_pk_desc* desc, hk_pk** out);
 void      hk_pk_free(hk_pk* pk);

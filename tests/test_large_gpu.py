@@ -243,3 +243,60 @@ def test_real_sha256_subcircuits_prove_and_verify(kind, ctx_bn254):
     hb, _ = ctx_bn254.witness_map(A, B, C, circ.N_INST, circ.n_c, fc.enc(bad), n_v=circ.n_v)
     assert fc.dec(hb)[-1] != 0
     dpk.free()
+
+
+def test_assignment_materialised_on_the_device_equals_the_host_bytes(ctx_bn254):
+    """hk_assignment_from_bits: one byte per variable + the full-width values over PCIe, Montgomery form in HBM - bit
+    for bit what the host-side table lookup (`assignment_bytes`) produces."""
+    from hekaton_system_amd.sha_circuit import ShaMerkleSubcircuit, example_witness, packed_assignments
+    circ = ShaMerkleSubcircuit("bn254", "parent", ns=1, n_portals=4)
+    ws = [example_witness(circ, seed=s, entry_chal=3, tr_chal=4) for s in (1, 2)]
+    want = circ.assignment_bytes(ws)
+    for k, (bits, cols, vals) in enumerate(packed_assignments(circ, ws)):
+        buf = ctx_bn254.assignment_from_bits(bits, cols, vals)
+        assert np.array_equal(buf.to_host(), want[k])
+        buf.free()
+    bad_cols = np.array([circ.n_v], np.uint32)
+    with pytest.raises(capi.HekatonError):
+        ctx_bn254.assignment_from_bits(np.zeros(circ.n_v, np.uint8), bad_cols, FrCodec("bn254").enc([1]))
+
+
+@pytest.mark.parametrize("kind", ["leaf", "parent"])
+def test_witness_generated_on_the_device_equals_the_host_trace(kind, ctx_bn254):
+    """hk_wprog_upload / hk_wprog_run (csrc/witness.cuh): the class's word program interpreted on the GPU from the
+    subcircuits' inputs gives, bit for bit, the assignments the numpy trace emits (themselves checked against hashlib
+    and the R1CS on the CPU); then a proof from the device-generated assignment verifies."""
+    from hekaton_system_amd.cp_groth16 import trapdoor_verify
+    from hekaton_system_amd.sha_circuit import (ShaMerkleSubcircuit, example_witness, full_values, program_inputs)
+    cname = "bn254"
+    fc = FrCodec(cname)
+    circ = ShaMerkleSubcircuit(cname, kind, ns=2, n_portals=4)
+    ws = [example_witness(circ, seed=s, entry_chal=31, tr_chal=41) for s in range(5)]
+    ops, refs, vmap = circ.tape.word_program(circ.n_v)
+    wp = ctx_bn254.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
+    cols, vals = full_values(circ, ws)
+    zdev = wp.run(program_inputs(circ, ws), cols, vals)
+    got = zdev.to_host().reshape(len(ws), -1)
+    want = circ.assignment_bytes(ws)
+    assert np.array_equal(got, want)
+    # a malformed program (operand reference beyond the values defined so far) is refused, not interpreted
+    bad = ops.copy()
+    k = int(np.nonzero(bad[:, 0] == 2)[0][0])
+    bad[k, 1] = circ.tape.n_values - 1
+    with pytest.raises(capi.HekatonError) as e:
+        ctx_bn254.wprog_upload(bad, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
+    assert e.value.status == capi.HK_ERR_ARG
+    # prove straight from the device-generated assignment of subcircuit 3
+    pk, td = generate_parameters(circ, cname, SeededRng(b"WPROG-CLASS-KEY!" * 2), ctx_bn254)
+    dpk = pk.upload(ctx_bn254)
+    z3 = capi.DeviceBuffer.from_host(ctx_bn254, got[3].copy())
+    z_ints = circ.assignment_ints(ws[3])[0]
+    kappa, r_, s_ = 5, 6, 7
+    com = dpk.commit(0, fc.enc(z_ints[circ.N_INST:circ.N_INST + circ.n0]), fc.enc1(kappa))
+    a, b, c = dpk.prove(z3, fc.enc1(r_), fc.enc1(s_), fc.enc([kappa]), n_v=circ.n_v)
+    A, B, C = pk.matrices
+    h_b, _m = ctx_bn254.witness_map(A, B, C, circ.N_INST, circ.n_c, z3, n_v=circ.n_v)
+    trapdoor_verify(ctx_bn254, cname, td, circ.N_INST, td.stage_ranges, z_ints, fc.dec(h_b), [com], [kappa], r_, s_, (a, b, c))
+    for x in (zdev, z3):
+        x.free()
+    wp.free(); dpk.free()

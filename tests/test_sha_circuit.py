@@ -100,3 +100,26 @@ def test_whole_job_witness_generation():
     w = job2.inputs(6)
     w["root"] = job.root
     assert _check_r1cs(circ, circ.assignment_ints(w)[0]) != []
+
+
+@pytest.mark.parametrize("kind", ["leaf", "parent", "root", "padding"])
+def test_word_program_reproduces_the_trace(kind):
+    """The word program the tape records (what the GPU interprets) + the column map + the host-side full-width values
+    rebuild exactly the assignment the numpy EVAL interpreter emits."""
+    from hekaton_system_amd.sha_circuit import full_values, program_inputs, run_word_program
+    circ = ShaMerkleSubcircuit("bn254", kind, 2, n_portals=4, last=(kind == "padding"))
+    ws = [example_witness(circ, seed=s, entry_chal=77, tr_chal=99) for s in (4, 5, 6)]
+    ops, refs, vmap = circ.tape.word_program(circ.n_v)
+    vals = run_word_program(ops, refs, circ.tape.n_values, program_inputs(circ, ws))
+    bits_ref, full_ref, _ = circ.witness_batch(ws)
+    mask = vmap != 0xffffffff
+    got = ((vals[vmap[mask] >> 5] >> (vmap[mask] & 31)[:, None]) & 1).T.astype(np.uint8)
+    assert np.array_equal(got, bits_ref[:, mask])
+    cols, fv = full_values(circ, ws)
+    assert sorted(cols.tolist()) == sorted([1, 2, 3] + list(full_ref.keys()))
+    assert set(np.nonzero(~mask)[0].tolist()) == set(cols.tolist()) | {0}
+    zs = circ.assignment_ints(ws)
+    fc = circ.fc
+    for b in range(3):
+        dec = fc.dec(fv[b])
+        assert all(dec[k] == zs[b][c] for k, c in enumerate(cols.tolist()))
