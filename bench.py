@@ -232,13 +232,19 @@ class Job:
                 zs.append(zb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, zb))
                 w0s.append(wb if args.host_inputs else capi.DeviceBuffer.from_host(self.ctx, wb))
                 seeds.append(ws)
-            zgen, wprog = [], None
+            extra = {}
             if args.witness_gen:
-                zgen = [capi.DeviceBuffer(self.ctx, circ.n_v * self.ctx.fr_bytes) for _ in range(len(members))]
+                # the requests of this rank's subcircuits (leaf bytes / child hashes / portal entries: INPUT data, made
+                # before the timed region) and the class's word program on the device
+                from hekaton_system_amd.sha_circuit import example_witness, program_inputs
+                ws = [example_witness(circ, seed=seeds[pos % len(seeds)], entry_chal=0x1234567, tr_chal=0x7654321)
+                      for pos in range(len(members))]
                 ops, refs, vmap = circ.tape.word_program(circ.n_v)
-                wprog = self.ctx.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
+                extra = dict(wg_ws=ws, wg_inputs=program_inputs(circ, ws),
+                             wprog=self.ctx.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs),
+                             zbig=capi.DeviceBuffer(self.ctx, len(members) * circ.n_v * self.ctx.fr_bytes))
             self.classes[rep] = dict(circ=circ, pk=pk, td=td, dpk=dpk, host=host, zs=zs, w0s=w0s, seeds=seeds,
-                                     members=members, matrices=pk.matrices, zgen=zgen, wprog=wprog)
+                                     members=members, matrices=pk.matrices, **extra)
             log("rank %d: %s class %d (%d subcircuits of this shard): key + %d assignments resident, %.1f s" % (
                 rank, curve, rep, len(members), len(zs), time.time() - t0))
         prepared["classes"] = None                   # the host copies are no longer needed
@@ -264,6 +270,7 @@ class Job:
         self.pool = ThreadPoolExecutor(max_workers=args.threads)
         self.accum_ms, self.accum_n, self.accum_h, self.phase = [], [], [], {}
         self.gather_s = 0.0
+        self.wg_s = 0.0
         self.last_records = None
         self.prev_records = None
 
@@ -286,16 +293,23 @@ class Job:
         rnd = self.rand[i]
         z = c["zs"][k]
         if self.args.witness_gen:
-            # witness generation inside the step: the subcircuit's inputs (a leaf / two child hashes) and its ~40
-            # full-width values go to the device; the class's word program produces the assignment in HBM
-            from hekaton_system_amd.sha_circuit import example_witness, full_values, program_inputs
-            circ = c["circ"]
-            w = example_witness(circ, seed=c["seeds"][k], entry_chal=0x1234567, tr_chal=0x7654321)
-            cols, vals = full_values(circ, [w])
-            z = c["wprog"].run(program_inputs(circ, [w]), cols, vals, out=c["zgen"][c["members"].index(i)])
+            z = c["zbig"].ptr + c["members"].index(i) * c["circ"].n_v * self.ctx.fr_bytes     # generated this step
         a, b, cc = c["dpk"].prove(z, rnd["r_b"], rnd["s_b"], rnd["kappa_b"], n_v=c["circ"].n_v)
         t = self.ctx.last_timings()
         return Stage1Response(i, Proof(a, b, cc, [com])).to_record(), t
+
+    def _generate_witnesses(self):
+        """Stage-1 witness generation for every subcircuit of the shard, one batched hk_wprog_run per proving-key class
+        (classes run concurrently): the host computes each subcircuit's ~40 full-width values (running evaluations),
+        the device everything else."""
+        from hekaton_system_amd.sha_circuit import full_values
+        t0 = time.time()
+
+        def one(c):
+            cols, vals = full_values(c["circ"], c["wg_ws"])
+            c["wprog"].run(c["wg_inputs"], cols, vals, out=c["zbig"])
+        list(self.pool.map(one, list(self.classes.values())))
+        return time.time() - t0
 
     def _gather(self, records):
         from hekaton_system_amd.worker import gather_records
@@ -310,6 +324,8 @@ class Job:
         all0 = self._gather([r for r, _ in r0])                           # node.rs:500-506
         assert len(all0) == self.n_total
         coms = [r[8:8 + g1b] for r, _ in r0]
+        if self.args.witness_gen:
+            self.wg_s += self._generate_witnesses()
         r1 = list(self.pool.map(self._stage1, zip(self.shard, coms)))
         all1 = self._gather([r for r, _ in r1])                           # node.rs:526-533
         assert len(all1) == self.n_total
@@ -363,7 +379,7 @@ class Job:
     def close(self):
         self.pool.shutdown()
         for c in self.classes.values():
-            for b in c["zs"] + c["w0s"] + c.get("zgen", []):
+            for b in c["zs"] + c["w0s"] + ([c["zbig"]] if c.get("zbig") else []):
                 if isinstance(b, self.capi.DeviceBuffer):
                     b.free()
             c["dpk"].free()
@@ -376,6 +392,7 @@ def timed_run(job, steps, warmup, barrier):
     for _ in range(warmup):
         job.step(False)
     job.gather_s = 0.0
+    job.wg_s = 0.0
     barrier()
     t0 = time.time()
     for _ in range(steps):
@@ -517,6 +534,7 @@ def main():
                        "exchange": "2 all_gathers per step (104 B + 328 B records), %s" % (backend if world > 1 else "local")},
             "roofline": roof,
             "per_rank_proofs_per_s": per_rank, "gather_ms_per_step": gather_ms,
+            "witness_gen_ms_per_step": (job.wg_s / args.steps * 1e3) if args.witness_gen else None,
             "timed_proofs_check": checks,
             "phase_ms_per_proof": {k: v / nprov for k, v in job.phase.items() if k.endswith("_ms")},
         }
