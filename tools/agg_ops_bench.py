@@ -70,6 +70,32 @@ def main():
         print("%-8s %8d %14.3f %16.3f %14.3f %18.3f" % (curve, n, t_one * 1e3, t_all * 1e3, t_c1 * 1e3, t_c16 * 1e3))
         for b in d1 + d2:
             b.free()
+    # ---- TIPP prove / verify (tipa.py): the whole GIPA recursion + KZG openings on random vectors
+    from hekaton_system_amd import aggregation as agg, tipa
+    print("%-8s %8s %14s %14s %14s" % ("tipp", "n", "setup ms", "prove ms", "verify ms"))
+    for n in (64, 256, 1024):
+        t0 = time.time()
+        srs = tipa.setup(ctx, curve, n, rnd.randrange(2, p["r"]), rnd.randrange(2, p["r"]))
+        t_setup = time.time() - t0
+        A = ctx.fixed_base(1, gen1, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)]))
+        B = ctx.fixed_base(2, gen2, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)]))
+        T = tipa.Tipp(ctx, curve)
+        com = T.com.commit_with_ip(srs.ck, A, B)
+        twist = rnd.randrange(2, p["r"])
+        tw = [pow(twist, i, p["r"]) for i in range(n)]
+        z = T.F.decode(ctx.multi_pairing(ctx.scalar_pairing(1, A, fc.enc(tw), n=n), B, n=n))
+        T.prove(srs, A, B, twist, com, z)
+        t0 = time.time()
+        proof = T.prove(srs, A, B, twist, com, z)
+        t_prove = time.time() - t0
+        vk = tipa.verifier_key(ctx, curve, srs)
+        t0 = time.time()
+        ok = T.verify(vk, com, z, twist, proof)
+        t_verify = time.time() - t0
+        assert ok
+        print("%-8s %8d %14.1f %14.1f %14.1f" % (curve, n, t_setup * 1e3, t_prove * 1e3, t_verify * 1e3))
+        for rb in srs.resident.values():
+            rb.free()
     print("%-8s %8s %12s %14s %12s %14s %18s" % ("group", "n", "msm ms", "resident ms", "cpu msm ms", "scalar_pair ms", "cpu scalar_pair ms"))
     for group in (1, 2):
         gen = fc.g1(p["g1"]) if group == 1 else fc.g2(p["g2"])
