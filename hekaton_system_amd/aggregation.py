@@ -55,16 +55,23 @@ class IppCom:
     """`Commitment<TIPPCommitment<E>>`: (T, U) in GT x GT and, for commit_with_ip, the inner product.  `+` multiplies
     in GT, `* k` raises to k (the reference's additive notation)."""
 
-    def __init__(self, F, t, u, ip=None):
-        self.F, self.t, self.u, self.ip = F, t, u, ip
+    def __init__(self, F, t, u, ip=None, ctx=None):
+        self.F, self.t, self.u, self.ip, self.ctx = F, t, u, ip, ctx
 
     def __add__(self, o):
         ip = None if (self.ip is None and o.ip is None) else self.F.mul(self.ip or self.F.one, o.ip or self.F.one)
-        return IppCom(self.F, self.F.mul(self.t, o.t), self.F.mul(self.u, o.u), ip)
+        return IppCom(self.F, self.F.mul(self.t, o.t), self.F.mul(self.u, o.u), ip, self.ctx or o.ctx)
 
     def __mul__(self, k):
-        ip = None if self.ip is None else self.F.pow(self.ip, k)
-        return IppCom(self.F, self.F.pow(self.t, k), self.F.pow(self.u, k), ip)
+        parts = [self.t, self.u] + ([self.ip] if self.ip is not None else [])
+        if self.ctx is not None:                       # GT powers on the GPU (hk_gt_pow), one wave per component
+            from .cp_groth16 import FrCodec
+            fc = FrCodec(self.ctx.curve)
+            out = self.ctx.gt_pow(np.frombuffer(b"".join(self.F.encode(x) for x in parts), np.uint8), fc.enc([k] * len(parts)))
+            res = [self.F.decode(out[i]) for i in range(len(parts))]
+        else:
+            res = [self.F.pow(x, k) for x in parts]
+        return IppCom(self.F, res[0], res[1], res[2] if len(res) > 2 else None, self.ctx)
 
     def __eq__(self, o):
         return self.t == o.t and self.u == o.u and (self.ip or self.F.one) == (o.ip or self.F.one)
@@ -81,12 +88,12 @@ class TIPPCommitment:
         """(e(A, v1), e(A, v2)) - aggregation.rs:97-100,168; coordinator.rs:339 (the super-commitment to all stage-0
         commitments, on the coordinator's critical path between the two rounds)."""
         out = self.ctx.pairing_products([left], [ck.v1, ck.v2], n=ck.n)
-        return IppCom(self.F, self.F.decode(out[0, 0]), self.F.decode(out[0, 1]))
+        return IppCom(self.F, self.F.decode(out[0, 0]), self.F.decode(out[0, 1]), ctx=self.ctx)
 
     def commit_only_right(self, ck, right):
         """(e(w1, B), e(w2, B)) - aggregation.rs:101-103."""
         out = self.ctx.pairing_products([ck.w1, ck.w2], [right], n=ck.n)
-        return IppCom(self.F, self.F.decode(out[0, 0]), self.F.decode(out[1, 0]))
+        return IppCom(self.F, self.F.decode(out[0, 0]), self.F.decode(out[1, 0]), ctx=self.ctx)
 
     def commit_with_ip(self, ck, left, right):
         """T = e(A, v1) e(w1, B), U = e(A, v2) e(w2, B), Z = e(A, B) - aggregation.rs:167."""
@@ -94,7 +101,7 @@ class TIPPCommitment:
         r = self.ctx.pairing_products([ck.w1, ck.w2], [right], n=ck.n)
         F = self.F
         return IppCom(F, F.mul(F.decode(l[0, 0]), F.decode(r[0, 0])), F.mul(F.decode(l[0, 1]), F.decode(r[1, 0])),
-                      F.decode(l[0, 2]))
+                      F.decode(l[0, 2]), ctx=self.ctx)
 
 
 class AggProvingKey:

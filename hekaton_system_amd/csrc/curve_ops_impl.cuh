@@ -116,6 +116,7 @@ struct Ops {
     static hk_status wprog_upload(hk_ctx*, const uint32_t*, size_t, const uint32_t*, size_t, const uint32_t*, size_t, size_t,
                                   size_t, hk_wprog**);
     static void wprog_free(hk_wprog*);
+    static hk_status gt_pow(hk_ctx*, const void*, const void*, size_t, void*);
     static hk_status wprog_run(hk_ctx*, const hk_wprog*, const uint32_t*, size_t, const uint32_t*, const void*, size_t, void*);
 
     static const CurveOps* table() {
@@ -123,7 +124,7 @@ struct Ops {
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
-                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run};
+                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow};
         return &t;
     }
 };

@@ -61,7 +61,9 @@ struct PairRun {
     // prod: n_l*n_r scratch, out: n_l*n_r results (device), out[a*n_r + b] = prod_i e(g1[a][i], g2[b][i]).
     static hk_status run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<Fp2<P>>* g2, u32 n, u32 n_l, u32 n_r,
                          Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out);
-    static size_t scratch_bytes(u32 n, u32 count);        // size of `miller` (lines + tree buffers, or Miller values)
+    static size_t scratch_bytes(u32 n, u32 count);
+    // out[e] = in[e]^scalars[e] (GT powers; device pointers)
+    static hk_status gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out);        // size of `miller` (lines + tree buffers, or Miller values)
 };
 
 }  // namespace hk

@@ -9,6 +9,21 @@ template <class P> struct PairLoopOf;
 template <> struct PairLoopOf<Bn254FqP> { static PairLoop get() { return pair_loop_bn254(); } };
 template <> struct PairLoopOf<Bls381FqP> { static PairLoop get() { return pair_loop_bls381(); } };
 
+template <class P> struct ScalarOfQ;
+template <> struct ScalarOfQ<Bn254FqP> { typedef Fp<Bn254FrP> type; };
+template <> struct ScalarOfQ<Bls381FqP> { typedef Fp<Bls381FrP> type; };
+
+template <class P>
+hk_status PairRun<P>::gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out) {
+    typedef typename ScalarOfQ<P>::type Fr;
+    if (n == 0) return HK_OK;
+    size_t lds = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
+    hipLaunchKernelGGL((k_gt_pow<P, Fr>), dim3(n), dim3(64), lds, s, in, (const Fr*)scalars_mont, n, out);
+    HK_DBG(s, "k_gt_pow");
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
 template <class P>
 size_t PairRun<P>::scratch_bytes(u32 n, u32 count) {
     PairSteps st = pair_steps(PairLoopOf<P>::get(), TowerParams<P>::TWIST_IS_D);

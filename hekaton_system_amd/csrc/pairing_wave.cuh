@@ -419,6 +419,36 @@ k_pair_tree(const Fp12<P>* __restrict__ in, u32 n, u32 c, Fp12<P>* __restrict__ 
     W::store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
 }
 
+// out[e] = in[e]^scalars[e] in Fq12 (GT): one wave per element, square-and-multiply on the wave multiplier.
+// (`Commitment * scalar` / `PairingOutput * scalar`: distributed-prover/src/aggregation.rs:171-174,328-332 and the
+// verifier side of TIPA - six GT powers per GIPA round.)
+template <class P, class Fr>
+__global__ void __launch_bounds__(64)
+k_gt_pow(const Fp12<P>* __restrict__ in, const Fr* __restrict__ scalars_mont, u32 n, Fp12<P>* __restrict__ out) {
+    extern __shared__ unsigned char pair_lds[];
+    typedef WaveF12<P> W;
+    typedef Fp<P> Fq;
+    __shared__ u32 kbits[Fr::N];
+    WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
+    Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    Fq *base = s, *acc = s + WV_SLOT;
+    if (blockIdx.x >= n) return;
+    if (threadIdx.x == 0) {
+        Fr k = Fr::from_mont(ld_vec(&scalars_mont[blockIdx.x]));
+        for (int i = 0; i < Fr::N; i++) kbits[i] = k.v[i];
+    }
+    W::load(base, &in[blockIdx.x]);
+    W::set_one(acc);
+    int top = -1;
+    for (int b = Fr::N * 32 - 1; b >= 0; b--)
+        if ((kbits[b >> 5] >> (b & 31)) & 1) { top = b; break; }
+    for (int b = top; b >= 0; b--) {
+        W::sqr(acc, acc, w);
+        if ((kbits[b >> 5] >> (b & 31)) & 1) W::mul(acc, acc, base, w);
+    }
+    W::store(&out[blockIdx.x], acc);
+}
+
 #endif  // __HIPCC__
 
 }  // namespace hk

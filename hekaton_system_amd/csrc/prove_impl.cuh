@@ -1026,6 +1026,28 @@ hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n
     return HK_OK;
 }
 
+template <class C>
+hk_status Ops<C>::gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars, size_t n, void* gt_out) {
+    typedef typename Fq::Params P;
+    typedef Fp12<P> GT;
+    if (n == 0) return HK_OK;
+    if (n >= (1u << 20)) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    HK_TRY(L->reserve(2 * al256(n * sizeof(GT)) + al256(n * sizeof(Fr)) + 4096));
+    const void *ind, *sd;
+    HK_TRY(to_device(L, gt_in, n * sizeof(GT), &ind));
+    HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sd));
+    bool out_dev = is_device_ptr(gt_out);
+    GT* od = out_dev ? (GT*)gt_out : L->alloc_n<GT>(n);
+    if (!od) return HK_ERR_NOMEM;
+    HK_TRY(PairRun<P>::gt_pow(L->stream, (const GT*)ind, sd, (u32)n, od));
+    if (!out_dev) HK_HIP(hipMemcpyAsync(gt_out, od, n * sizeof(GT), hipMemcpyDeviceToHost, L->stream));
+    HK_HIP(hipStreamSynchronize(L->stream));
+    return HK_OK;
+}
+
 // out[i] = in[i] * R (to_mont) or in[i] / R; memory canonical either way
 template <class F>
 __global__ void k_field_convert(const F* __restrict__ in, F* __restrict__ out, size_t n, int to_mont) {

@@ -23,6 +23,7 @@ GPU work per round: 10 multi-pairings of n/2 pairs (two hk_pairing_products call
 (hk_points_lincomb); at the end four MSMs over the resident SRS (hk_msm_bases).
 """
 import hashlib
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -129,6 +130,7 @@ class Tipp:
         self.F = GtField(curve)
         self.r = CURVE_PARAMS[curve]["r"]
         self.com = TIPPCommitment(ctx, curve)
+        self.pool = ThreadPoolExecutor(max_workers=6)      # independent GPU calls of a round go out together (one lane each)
 
     # ---- helpers ----------------------------------------------------------------------------------------
     def _halves(self, buf, size):
@@ -167,9 +169,10 @@ class Tipp:
             bL, bR = b[:h * g2b], b[h * g2b:]
             v1L, v1R, v2L, v2R = v1[:h * g2b], v1[h * g2b:], v2[:h * g2b], v2[h * g2b:]
             w1L, w1R, w2L, w2R = w1[:h * g1b], w1[h * g1b:], w2[:h * g1b], w2[h * g1b:]
-            # all ten multi-pairings of the round in two batched calls
-            pa = ctx.pairing_products([aR, aL], [v1L, v2L, bL, v1R, v2R, bR], n=h)
-            pw = ctx.pairing_products([w1R, w2R, w1L, w2L], [bL, bR], n=h)
+            # all ten multi-pairings of the round in two batched calls, issued together
+            fa = self.pool.submit(ctx.pairing_products, [aR, aL], [v1L, v2L, bL, v1R, v2R, bR], h)
+            fw = self.pool.submit(ctx.pairing_products, [w1R, w2R, w1L, w2L], [bL, bR], h)
+            pa, pw = fa.result(), fw.result()
             D = F.decode
             TL = F.mul(D(pa[0, 0]), D(pw[0, 0])); UL = F.mul(D(pa[0, 1]), D(pw[1, 0])); ZL = D(pa[0, 2])
             TR = F.mul(D(pa[1, 3]), D(pw[2, 1])); UR = F.mul(D(pa[1, 4]), D(pw[3, 1])); ZR = D(pa[1, 5])
@@ -178,10 +181,10 @@ class Tipp:
             c_inv = pow(c, -1, r)
             rounds.append(dict(TL=TL, UL=UL, ZL=ZL, TR=TR, UR=UR, ZR=ZR))
             challenges.append(c)
-            a = self._fold(1, aL, aR, c, h)
-            b = self._fold(2, bL, bR, c_inv, h)
-            v1, v2 = self._fold(2, v1L, v1R, c_inv, h), self._fold(2, v2L, v2R, c_inv, h)
-            w1, w2 = self._fold(1, w1L, w1R, c, h), self._fold(1, w2L, w2R, c, h)
+            folds = [self.pool.submit(self._fold, *args) for args in (
+                (1, aL, aR, c, h), (2, bL, bR, c_inv, h), (2, v1L, v1R, c_inv, h), (2, v2L, v2R, c_inv, h),
+                (1, w1L, w1R, c, h), (1, w2L, w2R, c, h))]
+            a, b, v1, v2, w1, w2 = (f.result() for f in folds)
             m = h
         tr.absorb(b"final", a, b, v1, v2, w1, w2)
         z = tr.challenge(b"kzg-point")
@@ -208,17 +211,25 @@ class Tipp:
         tr.absorb(b"instance", F.encode(com.t), F.encode(com.u), F.encode(z_ab), twist.to_bytes(32, "little"), n.to_bytes(8, "little"))
         T, U, Z = com.t, com.u, z_ab
         challenges = []
-        m = n
         if len(proof["rounds"]) != n.bit_length() - 1:
             return False
+        # the challenges depend on the proof's messages only, so every GT power of the fold check goes to the GPU in
+        # ONE batched call (hk_gt_pow: one wavefront per power)
+        bases, exps = [], []
         for rd in proof["rounds"]:
             tr.absorb(b"round", *(F.encode(rd[k]) for k in ("TL", "UL", "ZL", "TR", "UR", "ZR")))
             c = tr.challenge(b"c")
             c_inv = pow(c, -1, r)
             challenges.append(c)
-            T = F.mul(F.mul(F.pow(rd["TL"], c), T), F.pow(rd["TR"], c_inv))
-            U = F.mul(F.mul(F.pow(rd["UL"], c), U), F.pow(rd["UR"], c_inv))
-            Z = F.mul(F.mul(F.pow(rd["ZL"], c), Z), F.pow(rd["ZR"], c_inv))
+            bases += [rd["TL"], rd["UL"], rd["ZL"], rd["TR"], rd["UR"], rd["ZR"]]
+            exps += [c, c, c, c_inv, c_inv, c_inv]
+        if bases:
+            pw = ctx.gt_pow(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), fc.enc(exps))
+            for k in range(0, len(bases), 6):
+                tl, ul, zl, trr, ur, zr = (F.decode(pw[k + j]) for j in range(6))
+                T = F.mul(F.mul(tl, T), trr)
+                U = F.mul(F.mul(ul, U), ur)
+                Z = F.mul(F.mul(zl, Z), zr)
         a, b = proof["final_a"], proof["final_b"]
         (v1, v2), (w1, w2) = proof["final_v"], proof["final_w"]
         tr.absorb(b"final", a, b, v1, v2, w1, w2)

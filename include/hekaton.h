@@ -176,6 +176,10 @@ hk_status hk_multi_pairing(hk_ctx* ctx, const void* g1, const void* g2, size_t n
 hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2,
                               size_t n_rhs, size_t n, void* gt_out);
 hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt);
+/* gt_out[i] = gt_in[i]^scalars[i] in GT - `Commitment * scalar` (distributed-prover/src/aggregation.rs:171-174,328-332) and
+ * the six GT powers per round of the TIPA verifier; one wavefront per element.  gt_in, gt_out [h|d]: n GT elements;
+ * scalars_mont [h|d]: n Fr. */
+hk_status hk_gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, size_t n, void* gt_out);
 
 /* Element-wise linear combination of k <= 8 point vectors: out[i] = sum_j coeffs[j] * vecs[j][i], batch-normalised to
  * affine.  Replaces the aggregator's `prepared_input = s0 + s1*x0 + s2*x1 + s3*x2` (distributed-prover/src/

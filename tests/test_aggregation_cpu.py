@@ -1,0 +1,60 @@
+"""CPU: the host arithmetic of the aggregation mirror - GT (gt.py) against the tower oracle, the polynomial helpers of
+TIPP (tipa.py) against their definitions, the SHA-256 transcript's determinism."""
+import random
+
+import pytest
+
+from hekaton_system_amd import tipa
+from hekaton_system_amd.gt import GtField
+from oracle.pyref import pairing
+from oracle.pyref.params import CURVES
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_gt_arithmetic_matches_the_tower_oracle(cname):
+    cp = CURVES[cname]
+    T = pairing.tower(cname)
+    F = GtField(cname)
+    rnd = random.Random(8)
+    a = tuple(rnd.randrange(cp.q) for _ in range(12))
+    b = tuple(rnd.randrange(cp.q) for _ in range(12))
+    A, B = T.f12_from_flat(list(a)), T.f12_from_flat(list(b))
+    assert list(F.mul(a, b)) == T.f12_flat(T.f12_mul(A, B))
+    e = rnd.randrange(1 << 200)
+    assert list(F.pow(a, e)) == T.f12_flat(T.f12_pow(A, e))
+    assert list(F.conj(a)) == T.f12_flat(T.f12_conj(A))
+    assert F.decode(F.encode(a)) == a and F.mul(a, F.one) == a
+    g = tuple(T.f12_flat(T.pairing(cp.g1_gen, cp.g2_gen)))           # in GT the conjugate is the inverse
+    assert F.mul(g, F.conj(g)) == F.one
+
+
+def test_ipa_polynomial_and_division():
+    r = CURVES["bn254"].r
+    rnd = random.Random(3)
+    ch = [rnd.randrange(1, r) for _ in range(4)]
+    shift = rnd.randrange(1, r)
+    coeffs = tipa.ipa_polynomial_coeffs(ch, shift, r)
+    assert len(coeffs) == 16
+    for z in (0, 1, rnd.randrange(r)):
+        direct = 1
+        for k, c in enumerate(ch):
+            direct = direct * (1 + c * pow(shift * z, 1 << k, r)) % r
+        assert sum(c * pow(z, i, r) for i, c in enumerate(coeffs)) % r == direct == tipa.ipa_polynomial_eval(ch, shift, z, r)
+    # (X - z) q(X) + f(z) = f(X)
+    z = rnd.randrange(r)
+    q = tipa._divide_by_linear(coeffs, z, r)
+    assert len(q) == len(coeffs) and q[-1] == 0
+    fz = sum(c * pow(z, i, r) for i, c in enumerate(coeffs)) % r
+    x = rnd.randrange(r)
+    fx = sum(c * pow(x, i, r) for i, c in enumerate(coeffs)) % r
+    qx = sum(c * pow(x, i, r) for i, c in enumerate(q)) % r
+    assert ((x - z) * qx + fz) % r == fx
+
+
+def test_transcript_is_deterministic_and_order_sensitive():
+    r = CURVES["bn254"].r
+    t1, t2, t3 = tipa.Transcript(r), tipa.Transcript(r), tipa.Transcript(r)
+    t1.absorb(b"a", b"xy", b"z"); t2.absorb(b"a", b"xy", b"z"); t3.absorb(b"a", b"x", b"yz2")
+    c1, c2, c3 = t1.challenge(b"c"), t2.challenge(b"c"), t3.challenge(b"c")
+    assert c1 == c2 != c3 and 0 < c1 < r
+    assert t1.challenge(b"c") != c1

@@ -77,3 +77,22 @@ def test_multi_pairing_1024_bilinearity_and_cross_terms(ctx_bn254):
             want = T.f12_pow(e_gen, sum(x * y for x, y in zip(ka, kb)) % cp.r)
             assert E.f12_dec(out[i, j].tobytes()) == T.f12_flat(want), (i, j)
     assert E.f12_dec(out[0, 0].tobytes()) == got
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_gt_pow_matches_the_oracle(cname, ctx_bn254, ctx_bls):
+    """hk_gt_pow (one wavefront per element, square-and-multiply on the wave multiplier) against the tower oracle,
+    including exponents 0, 1 and r - 1 and a generic Fq12 base."""
+    ctx = _ctx(cname, ctx_bn254, ctx_bls)
+    cp = CURVES[cname]
+    T = pairing.tower(cname)
+    E = Enc(cp)
+    from hekaton_system_amd.cp_groth16 import FrCodec
+    fc = FrCodec(cname)
+    rnd = random.Random(21)
+    g = T.pairing(cp.g1_gen, cp.g2_gen)
+    bases = [g, g, g, T.f12_from_flat([rnd.randrange(cp.q) for _ in range(12)]), T.f12_pow(g, 12345)]
+    exps = [0, 1, cp.r - 1, rnd.randrange(cp.r), rnd.randrange(cp.r)]
+    out = ctx.gt_pow(np.frombuffer(b"".join(E.f12(T.f12_flat(b)) for b in bases), np.uint8), fc.enc(exps))
+    for k, (b, e) in enumerate(zip(bases, exps)):
+        assert E.f12_dec(out[k].tobytes()) == T.f12_flat(T.f12_pow(b, e)), k
