@@ -430,6 +430,97 @@ class ArkCodec:
         idx = r.u64()
         return Stage1Response(idx, self.read_proof(r))
 
+    # ---- coordinator requests (distributed-prover/src/coordinator.rs:195-261, 520-622), ROM circuits ----
+    # TranscriptEntry (transcript/mod.rs:216-233): tag byte 0 (Rom) | addr u64 | val Fr canonical.
+    def _fr_wire(self, v):
+        return int(v % self.r).to_bytes(self.frb, "little")
+
+    def _fr_read(self, r):
+        v = int.from_bytes(bytes(r.take(self.frb)), "little")
+        if v >= self.r:
+            raise SerializationError("InvalidData: field element not reduced")
+        return v
+
+    def _write_entry(self, w, e):
+        w.put(b"\x00")
+        w.u64(e[0])
+        w.put(self._fr_wire(e[1]))
+
+    def _read_entry(self, r):
+        tag = bytes(r.take(1))[0]
+        if tag != 0:
+            raise SerializationError("InvalidData: only ROM transcript entries (tag 0) are supported, got %d" % tag)
+        return (r.u64(), self._fr_read(r))
+
+    def stage0_request_to_wire(self, req):
+        """Stage0RequestRef (coordinator.rs:229-249): subcircuit_idx | Vec<TranscriptEntry> time | Vec<..> addr."""
+        w = Writer()
+        w.u64(req.subcircuit_idx)
+        for trace in (req.time_ordered_subtrace, req.addr_ordered_subtrace):
+            w.u64(len(trace))
+            for e in trace:
+                self._write_entry(w, e)
+        return w.getvalue()
+
+    def stage0_request_from_wire(self, buf):
+        from .worker import Stage0Request
+        r = Reader(buf)
+        idx = r.u64()
+        traces = []
+        for _ in range(2):
+            n = r.u64()
+            traces.append([self._read_entry(r) for _ in range(n)])
+        return Stage0Request(idx, traces[0], traces[1])
+
+    def stage1_request_to_wire(self, req):
+        """Stage1RequestRef (coordinator.rs:569-593): subcircuit_idx | cur_leaf | next_leaf_membership | root |
+        serialized_witnesses | circ_params.  cur_leaf = ExecTreeLeaf { evals: RunningEvaluation (tag 0 = Rom:
+        time_ordered_eval, addr_ordered_eval, Option<(entry_chal, tr_chal)>), last_subtrace_entry }.
+        next_leaf_membership = ark-crypto-primitives 0.4 `merkle_tree::Path { leaf_sibling_hash, auth_path: Vec<_>,
+        leaf_index: usize }` with Fr digests (Poseidon) - third-party layout, restated from memory."""
+        w = Writer()
+        w.u64(req.subcircuit_idx)
+        w.put(b"\x00")
+        w.put(self._fr_wire(req.time_ordered_eval))
+        w.put(self._fr_wire(req.addr_ordered_eval))
+        if req.challenges is None:
+            w.put(b"\x00")
+        else:
+            w.put(b"\x01")
+            w.put(self._fr_wire(req.challenges[0]))
+            w.put(self._fr_wire(req.challenges[1]))
+        self._write_entry(w, req.last_subtrace_entry)
+        w.put(self._fr_wire(req.leaf_sibling_hash))
+        w.u64(len(req.auth_path))
+        for h in req.auth_path:
+            w.put(self._fr_wire(h))
+        w.u64(req.leaf_index)
+        w.put(self._fr_wire(req.root))
+        write_bytes_vec(w, req.serialized_witnesses)
+        for v in req.circ_params:
+            w.u64(v)
+        return w.getvalue()
+
+    def stage1_request_from_wire(self, buf):
+        from .worker import Stage1Request
+        r = Reader(buf)
+        idx = r.u64()
+        if bytes(r.take(1))[0] != 0:
+            raise SerializationError("InvalidData: only ROM running evaluations (tag 0) are supported")
+        te, ae = self._fr_read(r), self._fr_read(r)
+        opt = bytes(r.take(1))[0]
+        if opt not in (0, 1):
+            raise SerializationError("InvalidData: Option tag")
+        chal = (self._fr_read(r), self._fr_read(r)) if opt else None
+        last = self._read_entry(r)
+        sib = self._fr_read(r)
+        path = [self._fr_read(r) for _ in range(r.u64())]
+        leaf_index = r.u64()
+        root = self._fr_read(r)
+        wit = bytes(read_bytes_vec(r))
+        params = (r.u64(), r.u64(), r.u64())
+        return Stage1Request(idx, 0, te, ae, chal, last, sib, path, leaf_index, root, wit, params)
+
     def stage0_response_size(self):
         return 8 + self.g1b + 32
 

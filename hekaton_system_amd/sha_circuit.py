@@ -13,7 +13,7 @@ FUNCTION of a subcircuit and the shape of its two-stage R1CS:
               truncated to 27 bytes, packed little-endian into a field element (vkd/util.rs:17-28 `digest_to_fpvar`)
               = the value it `set`s; parent: the two `get` values unpacked (`fpvar_to_digest`) -> 54 bytes -> the same
               chain; root: digest field == root; padding: the chain over 64 zero bytes; every subcircuit: running
-              products of (tr_chal - (addr + entry_chal * val)) over both subtraces (rom_transcript.rs:42-75), equal at
+              products of (tr_chal - (val + entry_chal * addr)) over both subtraces (rom_transcript.rs:77-107), equal at
               the last subcircuit, and value-consistency of equal addresses in the address-ordered slice.
     NOT reproduced: the Poseidon Merkle membership of the exec-tree leaf (subcircuit_circuit.rs:233-242) and the
               address-sortedness comparison - both third-party gadget territory; the evals enter and leave as witnesses.
@@ -392,7 +392,7 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
         assert t.n_wit == self.n0
         r_mod = self.r
         # ---- stage 1
-        # running evaluations (rom_transcript.rs:42-75): eval' = eval * (tr_chal - (addr + entry_chal * val))
+        # running evaluations (rom_transcript.rs:77-107): eval' = eval * (tr_chal - (val + entry_chal * addr))
         def running(entries, start_vals, key):
             ev_col = t.alloc_full(start_vals if ev else None)
             cur = start_vals
@@ -401,13 +401,13 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
             for k, (a_col, v_col) in enumerate(entries):
                 if ev:
                     ech, tr = inp["entry_chal"], inp["tr_chal"]
-                    e_vals = [(int(a) + ech * int(v)) % r_mod for a, v in zip(inp[key][k][0], inp[key][k][1])]
+                    e_vals = [(int(v) + ech * int(a)) % r_mod for a, v in zip(inp[key][k][0], inp[key][k][1])]
                     nxt = [c * ((tr - e) % r_mod) % r_mod for c, e in zip(cur, e_vals)]
                 else:
                     e_vals = nxt = None
                 e_col = t.alloc_full(e_vals)
                 n_col = t.alloc_full(nxt)
-                t.big_row([(1, ENTRY)], [(1, v_col)], [(1, e_col), (r_mod - 1, a_col)])
+                t.big_row([(1, ENTRY)], [(1, a_col)], [(1, e_col), (r_mod - 1, v_col)])
                 t.big_row([(1, ev_col)], [(1, TR), (r_mod - 1, e_col)], [(1, n_col)])
                 ev_col, cur = n_col, nxt
             return ev_col, cur
@@ -768,7 +768,7 @@ class ShaMerkleJob:
         self.addr = [srt[idx * n_portals:(idx + 1) * n_portals] for idx in range(n)]
         # running evaluations entering every subcircuit
         r, ech, tr = self.r, self.entry_chal, self.tr_chal
-        step = lambda cur, e: cur * ((tr - (e[0] + ech * e[1])) % r) % r
+        step = lambda cur, e: cur * ((tr - (e[1] + ech * e[0])) % r) % r
         self.time_eval0, self.addr_eval0 = [1], [1]
         for idx in range(n):
             t, a = self.time_eval0[-1], self.addr_eval0[-1]
@@ -877,7 +877,7 @@ def full_values(circ, inputs):
             vals.append(e0); c_local.append(col); col += 1
             cur = e0
             for a, v in w[key]:
-                e = (a + ech * v) % r
+                e = (v + ech * a) % r
                 cur = cur * ((tr - e) % r) % r
                 vals += [e, cur]; c_local += [col, col + 1]; col += 2
         for k in range(1, circ.n_addr):

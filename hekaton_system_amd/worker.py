@@ -23,7 +23,7 @@ from .cp_groth16 import CommitmentBuilder, Proof
 
 
 @dataclass
-class Stage0Request:                 # coordinator.rs:195-199 (subtraces carried as witness ints)
+class Stage0Request:                 # coordinator.rs:195-199; ROM entries as (addr u64, val int) pairs (rom_transcript.rs:222-226)
     subcircuit_idx: int
     time_ordered_subtrace: list = field(default_factory=list)
     addr_ordered_subtrace: list = field(default_factory=list)
@@ -47,9 +47,20 @@ class Stage0Response:                # worker.rs:20-25
 
 
 @dataclass
-class Stage1Request:                 # coordinator.rs:520-532 (only what the hot path consumes)
+class Stage1Request:                 # coordinator.rs:520-532
     subcircuit_idx: int
-    witness_seed: int = 0            # selects the synthetic subcircuit's stage-1 assignment
+    witness_seed: int = 0            # selects the synthetic subcircuit's stage-1 assignment (synthetic workloads)
+    # the reference's fields (ROM circuits, Poseidon exec tree over Fr), carried for the wire format:
+    time_ordered_eval: int = 1       # cur_leaf.evals (eval_tree.rs:53-58, rom_transcript.rs:18-27)
+    addr_ordered_eval: int = 1
+    challenges: tuple = None         # Option<(entry_chal, tr_chal)>
+    last_subtrace_entry: tuple = (0, 0)
+    leaf_sibling_hash: int = 0       # next_leaf_membership: ark-crypto-primitives merkle_tree::Path
+    auth_path: list = field(default_factory=list)
+    leaf_index: int = 0
+    root: int = 0
+    serialized_witnesses: bytes = b""
+    circ_params: tuple = (0, 0, 0)   # MerkleTreeCircuitParams { num_leaves, num_sha_iters_per_subcircuit, num_portals_per_subcircuit }
 
 
 @dataclass

@@ -206,3 +206,36 @@ def test_proving_keys_file_round_trip():
         pks.get_pk(9)
     with pytest.raises(SerializationError):
         ProvingKeys.deserialize(cd, blob[:-3])
+
+
+def test_request_records_roundtrip_and_layout():
+    """Stage0Request / Stage1Request framing (coordinator.rs:195-261,520-622; ROM circuits): hand-laid bytes, sizes,
+    round trips, and rejection of what ark's deserializer rejects (unreduced field element, RAM tag)."""
+    from hekaton_system_amd.ark_serialize import ArkCodec, SerializationError
+    from hekaton_system_amd.worker import Stage0Request, Stage1Request
+    from hekaton_system_amd.cp_groth16 import CURVE_PARAMS
+    codec = ArkCodec("bn254")
+    r = CURVE_PARAMS["bn254"]["r"]
+    req = Stage0Request(5, [(0x1122, 7), (9, r - 1)], [(9, r - 1)])
+    b = codec.stage0_request_to_wire(req)
+    want = (5).to_bytes(8, "little") + (2).to_bytes(8, "little") + b"\x00" + (0x1122).to_bytes(8, "little") + (7).to_bytes(32, "little") + \
+        b"\x00" + (9).to_bytes(8, "little") + (r - 1).to_bytes(32, "little") + (1).to_bytes(8, "little") + b"\x00" + (9).to_bytes(8, "little") + \
+        (r - 1).to_bytes(32, "little")
+    assert b == want and len(b) == 8 + 8 + 2 * 41 + 8 + 41
+    back = codec.stage0_request_from_wire(b)
+    assert (back.subcircuit_idx, back.time_ordered_subtrace, back.addr_ordered_subtrace) == (5, req.time_ordered_subtrace, req.addr_ordered_subtrace)
+    bad = bytearray(b); bad[16] = 1                                   # a RAM-tagged entry
+    with pytest.raises(SerializationError):
+        codec.stage0_request_from_wire(bytes(bad))
+    bad = bytearray(b); bad[25:57] = r.to_bytes(32, "little")          # val = r: not reduced
+    with pytest.raises(SerializationError):
+        codec.stage0_request_from_wire(bytes(bad))
+    s1 = Stage1Request(3, 0, time_ordered_eval=11, addr_ordered_eval=12, challenges=(13, 14), last_subtrace_entry=(4, 15),
+                       leaf_sibling_hash=16, auth_path=[17, 18, 19], leaf_index=6, root=20, serialized_witnesses=b"\xaa" * 64,
+                       circ_params=(32, 32, 4))
+    w = codec.stage1_request_to_wire(s1)
+    assert len(w) == 8 + (1 + 32 + 32 + 1 + 64) + 41 + 32 + (8 + 3 * 32) + 8 + 32 + (8 + 64) + 24
+    back = codec.stage1_request_from_wire(w)
+    assert back == s1
+    none = Stage1Request(3, 0, challenges=None)
+    assert codec.stage1_request_from_wire(codec.stage1_request_to_wire(none)).challenges is None
