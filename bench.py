@@ -314,7 +314,16 @@ class Job:
     def _gather(self, records):
         from hekaton_system_amd.worker import gather_records
         t0 = time.time()
-        out = gather_records(records, self.world, "cuda" if (self.world > 1 and self.backend == "nccl") else "cpu")
+        if getattr(self, "force_dist", False):
+            import torch
+            import torch.distributed as dist
+            import numpy as np
+            local = torch.from_numpy(np.stack(records)).to("cuda" if self.backend == "nccl" else "cpu")
+            bufs = [torch.empty_like(local)]
+            dist.all_gather(bufs, local)
+            out = bufs[0].cpu().numpy()
+        else:
+            out = gather_records(records, self.world, "cuda" if (self.world > 1 and self.backend == "nccl") else "cpu")
         self.gather_s += time.time() - t0
         return out
 
@@ -478,8 +487,12 @@ def main():
     backend = args.backend
     if backend == "auto":
         backend = "gloo" if (args.device is not None and world > 1) else "nccl"
-    if world > 1:
+    # HK_BENCH_FORCE_DIST=1: initialise the process group and route the gathers through it even with one rank (checks
+    # that RCCL and this library's streams coexist in one process on a 1-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("HK_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(dev)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
@@ -488,17 +501,18 @@ def main():
         log("rank %d/%d on device %d, %s backend sees %d ranks" % (rank, world, dev, backend, dist.get_world_size()))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     job = Job(args, prep, rank, world, dev, backend, keep_host=want_cpu)
+    job.force_dist = use_dist and world == 1
     circ = job.circ
     dt_local = timed_run(job, args.steps, args.warmup, barrier)
     dt = dt_local
     per_rank = [args.subcircuits * args.steps / dt_local]
     gather_ms = [job.gather_s / args.steps * 1e3]
-    if world > 1:
+    if use_dist:
         on = "cuda" if backend == "nccl" else "cpu"
         tt = torch.tensor([dt_local], dtype=torch.float64, device=on)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -566,7 +580,7 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if job is not None:
         job.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
