@@ -11,10 +11,10 @@
 
 All group arithmetic runs on the GPU: multi-pairings (hk_pairing_products), element-wise scalar multiplications
 (hk_scalar_pairing), element-wise linear combinations (hk_points_lincomb).  GT products / powers of commitments
-(three per job) are host arithmetic (gt.py).  NOT mirrored: the Fiat-Shamir transcript (merlin, third-party) - the
-challenges r (twist), s, t are arguments - and `TIPA::prove / verify` themselves (the GIPA recursion of the third-party
-`ripp` crate, absent from /root/reference; its building blocks are exactly the primitives above plus hk_msm_bases for the
-KZG openings).  PARITY UNPINNED for the snarkpack commitment layout (T = e(A, v1) e(w1, B), U = e(A, v2) e(w2, B),
+(three per job) are host arithmetic (gt.py).  The Fiat-Shamir challenges r (twist), s, t come from a merlin transcript
+(merlin.py, pinned by merlin's known-answer test) when `pt` is given, else they are arguments.  `TIPA::prove / verify`
+(the GIPA recursion of the third-party `ripp` crate, absent from /root/reference) are tipa.py; `agg_subcircuit_proofs`
+joins the two as aggregation.rs:138-345 does.  PARITY UNPINNED for the snarkpack commitment layout (T = e(A, v1) e(w1, B), U = e(A, v2) e(w2, B),
 restated from the SnarkPack paper); what the tests pin is the reference's own debug assertions
 (aggregation.rs:208-216,246-253,265-269) holding on proofs made by this prover.
 """
@@ -79,6 +79,13 @@ class IppCom:
     def to_bytes(self):
         return self.F.encode(self.t) + self.F.encode(self.u) + (self.F.encode(self.ip) if self.ip is not None else b"")
 
+    def serialize_uncompressed(self):
+        """Transcript bytes: each GT element as ark-serialize writes a `PairingOutput` (12 canonical little-endian Fq in
+        tower order), T then U then the inner product when present.  The member order of the third-party
+        `Commitment<TIPPCommitment<E>>` is an assumption (ripp is absent)."""
+        parts = [self.t, self.u] + ([self.ip] if self.ip is not None else [])
+        return b"".join(self.F.serialize(x) for x in parts)
+
 
 class TIPPCommitment:
     def __init__(self, ctx, curve):
@@ -127,9 +134,23 @@ class AggProvingKey:
         self.com_delta0 = self.com.commit_only_right(ck, self.delta0)                               # :102
         self.com_delta1 = self.com.commit_only_right(ck, self.delta1)                               # :103
 
-    def agg_front(self, super_com, proofs, pub_inputs, twist, s, t):
+    def agg_subcircuit_proofs(self, pt, super_com, proofs, pub_inputs, srs, tipp=None, check=True):
+        """aggregation.rs:138-345 whole: the challenges come from the merlin transcript `pt` (merlin.Transcript) exactly
+        where the reference draws them (:219-222, :276-278), then `TIPA::prove` and, as the reference does (:340), the
+        aggregator verifies its own proof.  Returns (tipp_proof, instance dict)."""
+        from . import tipa
+        tipp = tipp or tipa.Tipp(self.ctx, self.curve)
+        inst = self.agg_front(super_com, proofs, pub_inputs, pt=pt)
+        proof = tipp.prove(srs, inst["left"], inst["right"], inst["twist"], inst["commitment"], inst["output"])
+        if check:
+            vk = tipa.verifier_key(self.ctx, self.curve, srs)
+            assert tipp.verify(vk, inst["commitment"], inst["output"], inst["twist"], proof), "TIPA proof rejected (aggregation.rs:340)"
+        return proof, inst
+
+    def agg_front(self, super_com, proofs, pub_inputs, twist=None, s=None, t=None, pt=None):
         """aggregation.rs:138-330 up to the `TIPA::prove` call.  proofs: [cp_groth16.Proof] with one stage-0
-        commitment each; pub_inputs: 3 ints; twist, s, t: the Fiat-Shamir challenges (ints).  Returns a dict with the
+        commitment each; pub_inputs: 3 ints; the Fiat-Shamir challenges either as ints (twist, s, t) or drawn from the
+        merlin transcript `pt` at the reference's points.  Returns a dict with the
         TIPA instance (`output` = z_lr, `commitment` = com_lr, `twist`), the witness (`left`, `right`) and the 4 x 4
         `cross_terms`; raises AssertionError if the pairing-product equation of :265-269 fails."""
         ctx, F, ck, fc = self.ctx, self.F, self.ck, FrCodec(self.curve)
@@ -142,6 +163,11 @@ class AggProvingKey:
         com_ab = self.com.commit_with_ip(ck, a_vals, b_vals)                                        # :167
         com_c = self.com.commit_only_left(ck, c_vals)                                               # :168
         com_d = super_com
+        if pt is not None:                                                                          # :219-222
+            pt.append_serializable(b"AB-commitment", com_ab.serialize_uncompressed())
+            pt.append_serializable(b"C-commitment", com_c.serialize_uncompressed())
+            pt.append_serializable(b"D-commitment", com_d.serialize_uncompressed())
+            twist = pt.challenge_scalar(b"r-random-fiatshamir", r_mod)
         x = [v % r_mod for v in pub_inputs]
         com_prepared_input = self.com_s[0] + self.com_s[1] * x[0] + self.com_s[2] * x[1] + self.com_s[3] * x[2]   # :171-174
         prepared_input = ctx.points_lincomb(1, self.s, fc.enc([1] + x), n=n)                        # :192-205
@@ -156,6 +182,12 @@ class AggProvingKey:
         z_alpha_beta = F.decode(ctx.multi_pairing(alpha_r, self.beta, n=n))
         rhs = F.mul(F.mul(z_alpha_beta, z[1][1]), F.mul(z[2][2], z[3][3]))
         assert z[0][0] == rhs, "pairing-product equation of the twisted proofs does not hold (aggregation.rs:265-269)"
+        if pt is not None:                                                                          # :276-278
+            # Vec<Vec<PairingOutput>>: u64 length prefixes, elements canonical
+            ser = (4).to_bytes(8, "little") + b"".join((4).to_bytes(8, "little") + b"".join(F.serialize(e) for e in row) for row in z)
+            pt.append_serializable(b"cross-terms", ser)
+            s = pt.challenge_scalar(b"s-random-fiatshamir", r_mod)
+            t = pt.challenge_scalar(b"t-random-fiatshamir", r_mod)
         s2, s3, t2, t3 = s * s % r_mod, s * s * s % r_mod, t * t % r_mod, t * t * t % r_mod
         left = ctx.points_lincomb(1, [a_vals, prepared_input, d_vals, c_vals], fc.enc([1, s, s2, s3]), n=n)       # :293-310
         right = ctx.points_lincomb(2, [b_vals, self.h, self.delta0, self.delta1], fc.enc([1, t, t2, t3]), n=n)    # :311-326

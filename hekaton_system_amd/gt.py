@@ -28,6 +28,10 @@ class GtField:
     def encode(self, x):
         return b"".join((c * self.R % self.q).to_bytes(self.nb, "little") for c in x)
 
+    def serialize(self, x):
+        """ark-serialize (uncompressed = compressed for fields): 12 canonical little-endian Fq, tower order."""
+        return b"".join(c.to_bytes(self.nb, "little") for c in x)
+
     # ---- tower ----------------------------------------------------------------------------------------
     def _f2m(self, a, b):
         q = self.q

@@ -94,3 +94,53 @@ def test_tipp_closes_the_aggregation_of_real_proofs(ctx_bn254):
         dpk.free()
     for rb in srs.resident.values():
         rb.free()
+
+
+def test_agg_subcircuit_proofs_end_to_end_with_the_merlin_transcript(ctx_bn254):
+    """aggregation.rs:138-345 whole, challenges from a merlin transcript with the label the reference's e2e test uses
+    (coordinator.rs:411): prove, self-verify, and the verifier - re-deriving twist, s, t from the SAME public values -
+    accepts; a transcript with another label derives other challenges and the instance no longer matches."""
+    from hekaton_system_amd.merlin import Transcript as Merlin
+    ctx, cname, cp = ctx_bn254, "bn254", BN254
+    fc = FrCodec(cname)
+    family, n, reps = config_classes("tiny")
+    rnd = random.Random(5)
+    keys = {}
+    for rep in reps:
+        circ = make_config(cname, "tiny", rep)
+        pk, _td = generate_parameters(circ, cname, SeededRng(bytes([rep + 9]) * 32), ctx)
+        keys[rep] = (circ, pk, pk.upload(ctx))
+    proofs, coms, vks, pub = [], [], [], None
+    for idx in range(n):
+        circ, pk, dpk = keys[representative_subcircuit(family, n, idx)]
+        circ.set_witness_seed(3)
+        z = circ.assignment_ints()
+        pub = pub or z[1:4]
+        kappa = ChaCha12Rng(bytes([idx + 90]) * 32).fr(cp.r)
+        com = dpk.commit(0, circ.stage0_witness_bytes(), fc.enc1(kappa))
+        a, b, c = dpk.prove(circ.full_assignment_bytes(), fc.enc1(rnd.randrange(cp.r)), fc.enc1(rnd.randrange(cp.r)),
+                            fc.enc([kappa]), n_v=circ.n_v)
+        proofs.append(Proof(a, b, c, [com])); coms.append(com); vks.append(pk.vk)
+    srs = tipa.setup(ctx, cname, n, rnd.randrange(2, cp.r), rnd.randrange(2, cp.r))
+    apk = agg.AggProvingKey(ctx, cname, srs.ck, vks)
+    super_com = apk.com.commit_only_left(srs.ck, np.concatenate(coms))
+    proof, inst = apk.agg_subcircuit_proofs(Merlin(b"test-e2e"), super_com, proofs, pub, srs)
+    # determinism: the same transcript label gives the same challenges and the same instance
+    inst2 = apk.agg_front(super_com, proofs, pub, pt=Merlin(b"test-e2e"))
+    assert inst2["twist"] == inst["twist"] and inst2["output"] == inst["output"] and inst2["commitment"] == inst["commitment"]
+    # and they are the values a reader of the transcript derives from the public messages alone
+    pt = Merlin(b"test-e2e")
+    pt.append_serializable(b"AB-commitment", inst["com_ab"].serialize_uncompressed())
+    pt.append_serializable(b"C-commitment", inst["com_c"].serialize_uncompressed())
+    pt.append_serializable(b"D-commitment", super_com.serialize_uncompressed())
+    assert pt.challenge_scalar(b"r-random-fiatshamir", cp.r) == inst["twist"]
+    T = tipa.Tipp(ctx, cname)
+    vk = tipa.verifier_key(ctx, cname, srs)
+    assert T.verify(vk, inst["commitment"], inst["output"], inst["twist"], proof)
+    other = apk.agg_front(super_com, proofs, pub, pt=Merlin(b"another label"))
+    assert other["twist"] != inst["twist"]
+    assert not T.verify(vk, other["commitment"], other["output"], other["twist"], proof)
+    for _c, _pk, dpk in keys.values():
+        dpk.free()
+    for rb in srs.resident.values():
+        rb.free()
