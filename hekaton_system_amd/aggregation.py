@@ -87,6 +87,15 @@ class IppCom:
         return b"".join(self.F.serialize(x) for x in parts)
 
 
+def rom_challenges(super_com, r_mod):
+    """(entry_chal, tr_chal) of a ROM job: SHA-256 of a context string and the serialized commitment to all stage-0
+    commitments, reduced little-endian mod r (`RomRunningEvaluation::new`,
+    distributed-prover/src/transcript/rom_transcript.rs:42-75)."""
+    import hashlib
+    com_bytes = super_com.serialize_uncompressed()
+    return tuple(int.from_bytes(hashlib.sha256(tag + com_bytes).digest(), "little") % r_mod for tag in (b"entry_chal", b"tr_chal"))
+
+
 class TIPPCommitment:
     def __init__(self, ctx, curve):
         self.ctx, self.F = ctx, GtField(curve)

@@ -721,12 +721,13 @@ class ShaMerkleJob:
         root     get(left), get(right), placeholders ...         padding  placeholders ...
     address 0 = the placeholder portal (value 0), address 1 + j = the hash of the node proved by subcircuit j."""
 
-    def __init__(self, curve, n_subcircuits, ns, n_portals, leaves, entry_chal, tr_chal):
+    def __init__(self, curve, n_subcircuits, ns, n_portals, leaves, entry_chal=None, tr_chal=None):
+        """Without challenges only the stage-0 side exists (traces, `stage0_ints`); `set_challenges` - called by the
+        coordinator once the stage-0 commitments are in (coordinator.rs:315-352) - adds the running evaluations."""
         n = n_subcircuits
         assert n >= 4 and n & (n - 1) == 0 and len(leaves) == n // 2 and n_portals >= 3
         self.curve, self.n, self.ns, self.np_ = curve, n, ns, n_portals
         self.r = CURVE_PARAMS[curve]["r"]
-        self.entry_chal, self.tr_chal = entry_chal % self.r, tr_chal % self.r
         nl = n // 2
         # node j (subcircuit order) -> children; hashes
         self.kind = ["leaf"] * nl + ["parent"] * (n - 2 - nl) + ["root", "padding"]
@@ -766,7 +767,19 @@ class ShaMerkleJob:
         order = sorted(range(len(flat)), key=lambda k: (flat[k][0], k))
         srt = [flat[k] for k in order]
         self.addr = [srt[idx * n_portals:(idx + 1) * n_portals] for idx in range(n)]
-        # running evaluations entering every subcircuit
+        self.entry_chal = self.tr_chal = None
+        if entry_chal is not None:
+            self.set_challenges(entry_chal, tr_chal)
+
+    def stage0_ints(self, idx):
+        """The subcircuit's stage-0 witness (what `process_stage0_request` commits to, worker.rs:91-146): (addr, val) of
+        its time-ordered then its address-ordered entries, the variable order of `ShaMerkleSubcircuit._program`."""
+        return [x for e in self.time[idx] for x in e] + [x for e in self.addr[idx] for x in e]
+
+    def set_challenges(self, entry_chal, tr_chal):
+        """Running evaluations entering every subcircuit (coordinator.rs:125-160 `generate_exec_tree`)."""
+        n = self.n
+        self.entry_chal, self.tr_chal = entry_chal % self.r, tr_chal % self.r
         r, ech, tr = self.r, self.entry_chal, self.tr_chal
         step = lambda cur, e: cur * ((tr - (e[1] + ech * e[0])) % r) % r
         self.time_eval0, self.addr_eval0 = [1], [1]

@@ -58,3 +58,22 @@ def test_transcript_is_deterministic_and_order_sensitive():
     c1, c2, c3 = t1.challenge(b"c"), t2.challenge(b"c"), t3.challenge(b"c")
     assert c1 == c2 != c3 and 0 < c1 < r
     assert t1.challenge(b"c") != c1
+
+
+def test_rom_challenges_are_the_sha256_of_the_serialized_commitment():
+    """rom_transcript.rs:42-75: SHA-256(context || uncompressed commitment), little-endian, reduced mod r."""
+    import hashlib
+    from hekaton_system_amd.aggregation import IppCom, rom_challenges
+    from hekaton_system_amd.cp_groth16 import CURVE_PARAMS
+    from hekaton_system_amd.gt import GtField
+    F = GtField("bn254")
+    r = CURVE_PARAMS["bn254"]["r"]
+    t = tuple(range(1, 13))
+    u = tuple(range(101, 113))
+    com = IppCom(F, t, u)
+    ser = com.serialize_uncompressed()
+    assert len(ser) == 2 * 12 * 32 and ser[:32] == (1).to_bytes(32, "little") and ser[384:416] == (101).to_bytes(32, "little")
+    e, tr = rom_challenges(com, r)
+    assert e == int.from_bytes(hashlib.sha256(b"entry_chal" + ser).digest(), "little") % r
+    assert tr == int.from_bytes(hashlib.sha256(b"tr_chal" + ser).digest(), "little") % r
+    assert e != tr and rom_challenges(IppCom(F, u, t), r) != (e, tr)
