@@ -96,6 +96,51 @@ def main():
         print("%-8s %8d %14.1f %14.1f %14.1f" % (curve, n, t_setup * 1e3, t_prove * 1e3, t_verify * 1e3))
         for rb in srs.resident.values():
             rb.free()
+    # ---- the aggregator's whole serial tail on REAL proofs (tiny subcircuits, 5 key classes by the big-merkle index map):
+    # AggProvingKey::new (7 commitments), the super commitment, agg_subcircuit_proofs = front half + TIPA prove + verify
+    from hekaton_system_amd.chacha import ChaCha12Rng
+    from hekaton_system_amd.cp_groth16 import Proof, SeededRng, generate_parameters
+    from hekaton_system_amd.merlin import Transcript as Merlin
+    from hekaton_system_amd.workload import make_config, representative_subcircuit, unique_subcircuits
+    print("%-8s %8s %14s %14s %12s %12s %12s %12s" % ("job", "n", "agg key ms", "super com ms", "front ms", "prove ms", "verify ms", "total ms"))
+    for n in (64, 1024):
+        keys = {}
+        for rep in unique_subcircuits("big-merkle", n):
+            circ = make_config(curve, "tiny", rep)
+            pk, _td = generate_parameters(circ, curve, SeededRng(bytes([rep % 251 + 1]) * 32), ctx)
+            circ.set_witness_seed(5)
+            keys[rep] = (circ, pk, pk.upload(ctx), circ.full_assignment_bytes(), circ.stage0_witness_bytes())
+        proofs, coms, vks, pub = [], [], [], None
+        for idx in range(n):
+            circ, pk, dpk, zb, w0 = keys[representative_subcircuit("big-merkle", n, idx)]
+            pub = pub or circ.assignment_ints()[1:4]
+            kappa = ChaCha12Rng(idx.to_bytes(4, "little") * 8).fr(p["r"])
+            com = dpk.commit(0, w0, fc.enc1(kappa))
+            a, b, c = dpk.prove(zb, fc.enc1(rnd.randrange(p["r"])), fc.enc1(rnd.randrange(p["r"])), fc.enc([kappa]), n_v=circ.n_v)
+            proofs.append(Proof(a, b, c, [com])); coms.append(com); vks.append(pk.vk)
+        srs = tipa.setup(ctx, curve, n, rnd.randrange(2, p["r"]), rnd.randrange(2, p["r"]))
+        t0 = time.time()
+        apk = agg.AggProvingKey(ctx, curve, srs.ck, vks)
+        t_key = time.time() - t0
+        t0 = time.time()
+        super_com = apk.com.commit_only_left(srs.ck, np.concatenate(coms))
+        t_super = time.time() - t0
+        T = tipa.Tipp(ctx, curve)
+        vk = tipa.verifier_key(ctx, curve, srs)
+        apk.agg_subcircuit_proofs(Merlin(b"bench"), super_com, proofs, pub, srs, tipp=T)          # warm
+        t0 = time.time()
+        inst = apk.agg_front(super_com, proofs, pub, pt=Merlin(b"bench"))
+        t1 = time.time()
+        proof = T.prove(srs, inst["left"], inst["right"], inst["twist"], inst["commitment"], inst["output"])
+        t2 = time.time()
+        assert T.verify(vk, inst["commitment"], inst["output"], inst["twist"], proof)
+        t3 = time.time()
+        print("%-8s %8d %14.1f %14.1f %12.1f %12.1f %12.1f %12.1f" % (curve, n, t_key * 1e3, t_super * 1e3, (t1 - t0) * 1e3,
+                                                                   (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) * 1e3))
+        for _c, _pk, dpk, _z, _w in keys.values():
+            dpk.free()
+        for rb in srs.resident.values():
+            rb.free()
     print("%-8s %8s %12s %14s %12s %14s %18s" % ("group", "n", "msm ms", "resident ms", "cpu msm ms", "scalar_pair ms", "cpu scalar_pair ms"))
     for group in (1, 2):
         gen = fc.g1(p["g1"]) if group == 1 else fc.g2(p["g2"])
