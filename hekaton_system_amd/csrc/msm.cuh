@@ -266,6 +266,12 @@ __device__ __forceinline__ u32 msm_find_bucket(const u32* __restrict__ start, u3
 // the accumulate loop inlines the P == Q corner of the mixed add for every base field (G1); G2 follows the default
 template <class F> struct AccumInlineCorner { static constexpr bool value = F::Params::N <= 8; };
 template <class P> struct AccumInlineCorner<Fp<P>> { static constexpr bool value = true; };
+#ifndef HK_ACCUM_PREFETCH
+#define HK_ACCUM_PREFETCH 1            // 0 = off, 1 = 8-limb G1 only (shipped: H launch alone 3.86 -> 3.5-3.7 ms, bench
+                                       // throughput unchanged), 2 = every G1, 3 = G1 and 8-limb G2 (build-time knob)
+#endif
+template <class F> struct AccumPrefetch { static constexpr bool value = HK_ACCUM_PREFETCH >= 3 && F::Params::N <= 8; };
+template <class P> struct AccumPrefetch<Fp<P>> { static constexpr bool value = HK_ACCUM_PREFETCH >= 2 || (HK_ACCUM_PREFETCH == 1 && P::N <= 8); };
 template <class F> struct AccumOcc { static constexpr int waves = 1; };
 #ifndef HK_ACCUM_WAVES_G1_8LIMB
 #define HK_ACCUM_WAVES_G1_8LIMB 4      // build-time experiment knob (make EXTRA=-DHK_ACCUM_WAVES_G1_8LIMB=5)
@@ -297,6 +303,41 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
     // boundary partials go straight to memory when they become known (keeping a second XYZZ value
     // live across the loop costs 32+ VGPRs, i.e. a wave of occupancy)
     st_vec(&ppts[2 * t], XYZZ<F>::inf());
+    if constexpr (AccumPrefetch<F>::value) {
+        // software pipeline, two deep: the entry of step pos + 2 and the 64-byte table row of step pos + 1 are
+        // requested before the mixed add of step pos, so neither link of the dependent chain entry -> row -> add
+        // stands between two adds of this wave
+        u32 e_n = 0, e_nn = 0;
+        bool v_n = false;
+        Affine<F> P_n;
+        auto request_row = [&](u32 e) {
+            e_n = e;
+            u32 g = (e & 0x7fffffffu) >> p.gshift;
+            u32 i = e & ((1u << p.gshift) - 1u);
+            v_n = i >= idx_off && i - idx_off < n_bases;
+            P_n = ld_vec(&bases[v_n ? (size_t)g * n_bases + (i - idx_off) : 0]);
+        };
+        if (pos < end) request_row(sorted[pos]);
+        if (pos + 1 < end) e_nn = sorted[pos + 1];
+        for (; pos < end; pos++) {
+            Affine<F> P = P_n;
+            u32 e = e_n;
+            bool v = v_n;
+            if (pos + 1 < end) request_row(e_nn);
+            if (pos + 2 < end) e_nn = sorted[pos + 2];
+            if (pos == boundary) {
+                if (first && head_partial) st_vec(&ppts[2 * t], acc);
+                else st_vec(&buckets[b], acc);
+                first = false;
+                acc = XYZZ<F>::inf();
+                do { b++; boundary = start[b + 1]; } while (boundary <= pos);
+            }
+            if (v) {
+                if (e >> 31) P.y = F::neg(P.y);
+                acc = ec_madd<F, AccumInlineCorner<F>::value>(acc, P);
+            }
+        }
+    } else
     for (; pos < end; pos++) {
         if (pos == boundary) {
             // bucket b ended exactly here
