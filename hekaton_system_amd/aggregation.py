@@ -18,6 +18,7 @@ joins the two as aggregation.rs:138-345 does.  PARITY UNPINNED for the snarkpack
 restated from the SnarkPack paper); what the tests pin is the reference's own debug assertions
 (aggregation.rs:208-216,246-253,265-269) holding on proofs made by this prover.
 """
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
 import numpy as np
@@ -72,6 +73,35 @@ class IppCom:
         else:
             res = [self.F.pow(x, k) for x in parts]
         return IppCom(self.F, res[0], res[1], res[2] if len(res) > 2 else None, self.ctx)
+
+    @staticmethod
+    def lincomb(terms):
+        """sum_k com_k * scalar_k (additive notation) with every GT power of the sum in ONE hk_gt_pow call.
+        terms: [(IppCom, int scalar or None for 1)]."""
+        F = terms[0][0].F
+        ctx = next((c.ctx for c, _ in terms if c.ctx is not None), None)
+        bases, exps, slots = [], [], []
+        for com, k in terms:
+            parts = [com.t, com.u] + ([com.ip] if com.ip is not None else [])
+            if k is None:
+                slots.append(parts)
+                continue
+            slots.append([len(bases) + j for j in range(len(parts))])
+            bases += parts
+            exps += [k] * len(parts)
+        if bases:
+            if ctx is not None:
+                from .cp_groth16 import FrCodec
+                out = ctx.gt_pow(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), FrCodec(ctx.curve).enc(exps))
+                pw = [F.decode(out[i]) for i in range(len(bases))]
+            else:
+                pw = [F.pow(b, e) for b, e in zip(bases, exps)]
+        acc = None
+        for (com, k), sl in zip(terms, slots):
+            parts = sl if k is None else [pw[i] for i in sl]
+            term = IppCom(F, parts[0], parts[1], parts[2] if len(parts) > 2 else None, ctx)
+            acc = term if acc is None else acc + term
+        return acc
 
     def __eq__(self, o):
         return self.t == o.t and self.u == o.u and (self.ip or self.F.one) == (o.ip or self.F.one)
@@ -128,6 +158,7 @@ class AggProvingKey:
         self.ctx, self.curve, self.ck = ctx, curve, ck
         self.com = TIPPCommitment(ctx, curve)
         self.F = self.com.F
+        self.pool = ThreadPoolExecutor(max_workers=6)
         g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
         cat = lambda xs: np.concatenate([np.asarray(x, np.uint8) for x in xs])
         self.n = len(vks)
@@ -138,10 +169,10 @@ class AggProvingKey:
         self.delta1 = cat([vk.deltas_h[g2b:2 * g2b] for vk in vks])                                 # :90
         self.alpha = cat([vk.alpha_g for vk in vks])                                                # :91
         self.beta = cat([vk.beta_h for vk in vks])                                                  # :92
-        self.com_s = [self.com.commit_only_left(ck, v) for v in self.s]                             # :97-100
-        self.com_h = self.com.commit_only_right(ck, self.h)                                         # :101
-        self.com_delta0 = self.com.commit_only_right(ck, self.delta0)                               # :102
-        self.com_delta1 = self.com.commit_only_right(ck, self.delta1)                               # :103
+        fs = [self.pool.submit(self.com.commit_only_left, ck, v) for v in self.s]                   # :97-100
+        fr = [self.pool.submit(self.com.commit_only_right, ck, v) for v in (self.h, self.delta0, self.delta1)]   # :101-103
+        self.com_s = [f.result() for f in fs]
+        self.com_h, self.com_delta0, self.com_delta1 = (f.result() for f in fr)
 
     def agg_subcircuit_proofs(self, pt, super_com, proofs, pub_inputs, srs, tipp=None, check=True):
         """aggregation.rs:138-345 whole: the challenges come from the merlin transcript `pt` (merlin.Transcript) exactly
@@ -169,26 +200,31 @@ class AggProvingKey:
         cat = lambda xs: np.concatenate([np.asarray(x, np.uint8) for x in xs])
         a_vals, b_vals = cat([p.a for p in proofs]), cat([p.b for p in proofs])
         c_vals, d_vals = cat([p.c for p in proofs]), cat([p.ds[0] for p in proofs])
-        com_ab = self.com.commit_with_ip(ck, a_vals, b_vals)                                        # :167
-        com_c = self.com.commit_only_left(ck, c_vals)                                               # :168
-        com_d = super_com
+        # independent GPU calls of a phase go out together (one lane each), as in tipa.Tipp
+        go = self.pool.submit
+        x = [v % r_mod for v in pub_inputs]
+        f_ab = go(self.com.commit_with_ip, ck, a_vals, b_vals)                                      # :167
+        f_c = go(self.com.commit_only_left, ck, c_vals)                                             # :168
+        f_in = go(ctx.points_lincomb, 1, self.s, fc.enc([1] + x), n)                                # :192-205
+        f_cin = go(IppCom.lincomb, [(self.com_s[0], None), (self.com_s[1], x[0]), (self.com_s[2], x[1]), (self.com_s[3], x[2])])  # :171-174
+        com_ab, com_c, com_d = f_ab.result(), f_c.result(), super_com
         if pt is not None:                                                                          # :219-222
             pt.append_serializable(b"AB-commitment", com_ab.serialize_uncompressed())
             pt.append_serializable(b"C-commitment", com_c.serialize_uncompressed())
             pt.append_serializable(b"D-commitment", com_d.serialize_uncompressed())
             twist = pt.challenge_scalar(b"r-random-fiatshamir", r_mod)
-        x = [v % r_mod for v in pub_inputs]
-        com_prepared_input = self.com_s[0] + self.com_s[1] * x[0] + self.com_s[2] * x[1] + self.com_s[3] * x[2]   # :171-174
-        prepared_input = ctx.points_lincomb(1, self.s, fc.enc([1] + x), n=n)                        # :192-205
+        prepared_input, com_prepared_input = f_in.result(), f_cin.result()
         tw = [1] * n                                                                                # :224 structured_scalar_power
         for i in range(1, n):
             tw[i] = tw[i - 1] * twist % r_mod
         twb = fc.enc(tw)
-        a_r, c_r, d_r, alpha_r, input_r = (ctx.scalar_pairing(1, v, twb, n=n)                       # :236-242
-                                           for v in (a_vals, c_vals, d_vals, self.alpha, prepared_input))
-        cross = ctx.pairing_products([a_r, input_r, d_r, c_r], [b_vals, self.h, self.delta0, self.delta1], n=n)   # :255-263
+        a_r, c_r, d_r, alpha_r, input_r = (f.result() for f in [go(ctx.scalar_pairing, 1, v, twb, n)       # :236-242
+                                                                for v in (a_vals, c_vals, d_vals, self.alpha, prepared_input)])
+        f_cross = go(ctx.pairing_products, [a_r, input_r, d_r, c_r], [b_vals, self.h, self.delta0, self.delta1], n)   # :255-263
+        f_ab_z = go(ctx.multi_pairing, alpha_r, self.beta, n)
+        cross = f_cross.result()
         z = [[F.decode(cross[i, j]) for j in range(4)] for i in range(4)]
-        z_alpha_beta = F.decode(ctx.multi_pairing(alpha_r, self.beta, n=n))
+        z_alpha_beta = F.decode(f_ab_z.result())
         rhs = F.mul(F.mul(z_alpha_beta, z[1][1]), F.mul(z[2][2], z[3][3]))
         assert z[0][0] == rhs, "pairing-product equation of the twisted proofs does not hold (aggregation.rs:265-269)"
         if pt is not None:                                                                          # :276-278
@@ -198,11 +234,13 @@ class AggProvingKey:
             s = pt.challenge_scalar(b"s-random-fiatshamir", r_mod)
             t = pt.challenge_scalar(b"t-random-fiatshamir", r_mod)
         s2, s3, t2, t3 = s * s % r_mod, s * s * s % r_mod, t * t % r_mod, t * t * t % r_mod
-        left = ctx.points_lincomb(1, [a_vals, prepared_input, d_vals, c_vals], fc.enc([1, s, s2, s3]), n=n)       # :293-310
-        right = ctx.points_lincomb(2, [b_vals, self.h, self.delta0, self.delta1], fc.enc([1, t, t2, t3]), n=n)    # :311-326
-        com_lr = (com_ab + com_prepared_input * s + com_d * s2 + com_c * s3) + \
-                 (self.com_h * t + self.com_delta0 * t2 + self.com_delta1 * t3)                     # :328-332
+        f_left = go(ctx.points_lincomb, 1, [a_vals, prepared_input, d_vals, c_vals], fc.enc([1, s, s2, s3]), n)       # :293-310
+        f_right = go(ctx.points_lincomb, 2, [b_vals, self.h, self.delta0, self.delta1], fc.enc([1, t, t2, t3]), n)    # :311-326
+        f_lr = go(IppCom.lincomb, [(com_ab, None), (com_prepared_input, s), (com_d, s2), (com_c, s3),
+                                   (self.com_h, t), (self.com_delta0, t2), (self.com_delta1, t3)])  # :328-332
+        left, right = f_left.result(), f_right.result()
         left_r = ctx.scalar_pairing(1, left, twb, n=n)                                              # twisted_inner_product
         z_lr = F.decode(ctx.multi_pairing(left_r, right, n=n))                                      # :334
+        com_lr = f_lr.result()
         return dict(size=n, output=z_lr, commitment=com_lr, twist=twist, left=left, right=right, cross_terms=z,
                     com_ab=com_ab, com_c=com_c, prepared_input=prepared_input)

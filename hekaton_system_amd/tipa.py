@@ -235,33 +235,38 @@ class Tipp:
         tr.absorb(b"final", a, b, v1, v2, w1, w2)
         z = tr.challenge(b"kzg-point")
         D = F.decode
-        e = lambda p, q: D(ctx.multi_pairing(p, q, n=1))
-        # the folded instance
-        if e(a, b) != Z:
-            return False
-        if F.mul(e(a, v1), e(w1, b)) != T or F.mul(e(a, v2), e(w2, b)) != U:
-            return False
-        # the folded keys are the claimed polynomial images of the SRS (KZG checks)
+        go = self.pool.submit
+        # every remaining check is independent of the others: the element-wise combinations go out together, then the
+        # pairings - the five of the folded instance as one 3 x 3 batch, each KZG check as one 2 x 2 batch
         ch_rev = challenges[::-1]
         chi_rev = [pow(c, -1, r) for c in ch_rev]
         r_inv = pow(twist, -1, r)
         fvz = ipa_polynomial_eval(chi_rev, 1, z, r)
         fwz = pow(z, n, r) * ipa_polynomial_eval(ch_rev, r_inv, z, r) % r
-        one = F.one
         neg = lambda x: (r - x) % r
+        f_inst = go(ctx.pairing_products, [a, w1, w2], [b, v1, v2], 1)
         # v:  e(g, v' - f_v(z) h) = e(g^tau - z g, pi)   <=>   e(g, v' - f_v(z) h) * e(z g - g^tau, pi) = 1
+        v_checks = []
         for key, vfin, pi in (("g_alpha", v1, proof["open_v"][0]), ("g_beta", v2, proof["open_v"][1])):
-            lhs2 = ctx.points_lincomb(2, [vfin, vk["h"]], fc.enc([1, neg(fvz)]), n=1)
-            lhs1 = ctx.points_lincomb(1, [vk["g"], vk[key]], fc.enc([z, neg(1)]), n=1)
-            if D(ctx.pairing_products([vk["g"]], [lhs2], n=1)[0, 0]) != F.conj(D(ctx.pairing_products([lhs1], [pi], n=1)[0, 0])):
-                return False
+            v_checks.append((go(ctx.points_lincomb, 2, [vfin, vk["h"]], fc.enc([1, neg(fvz)]), 1),
+                             go(ctx.points_lincomb, 1, [vk["g"], vk[key]], fc.enc([z, neg(1)]), 1), pi))
         # w:  e(w' - f_w(z) g, h) = e(pi, h^tau - z h)
+        w_checks = []
         for key, wfin, pi in (("h_alpha", w1, proof["open_w"][0]), ("h_beta", w2, proof["open_w"][1])):
-            lhs1 = ctx.points_lincomb(1, [wfin, vk["g"]], fc.enc([1, neg(fwz)]), n=1)
-            rhs2 = ctx.points_lincomb(2, [vk[key], vk["h"]], fc.enc([1, neg(z)]), n=1)
-            if D(ctx.pairing_products([lhs1], [vk["h"]], n=1)[0, 0]) != D(ctx.pairing_products([pi], [rhs2], n=1)[0, 0]):
-                return False
-        return True
+            w_checks.append((go(ctx.points_lincomb, 1, [wfin, vk["g"]], fc.enc([1, neg(fwz)]), 1),
+                             go(ctx.points_lincomb, 2, [vk[key], vk["h"]], fc.enc([1, neg(z)]), 1), pi))
+        f_v = [go(ctx.pairing_products, [vk["g"], l1.result()], [l2.result(), pi], 1) for l2, l1, pi in v_checks]
+        f_w = [go(ctx.pairing_products, [l1.result(), pi], [vk["h"], r2.result()], 1) for l1, r2, pi in w_checks]
+        pi_ = f_inst.result()
+        ok = D(pi_[0, 0]) == Z                                                  # the folded instance: e(a, b) = Z
+        ok &= F.mul(D(pi_[0, 1]), D(pi_[1, 0])) == T and F.mul(D(pi_[0, 2]), D(pi_[2, 0])) == U
+        for f in f_v:                                                           # e(g, lhs2) == conj(e(lhs1, pi))
+            pr = f.result()
+            ok &= D(pr[0, 0]) == F.conj(D(pr[1, 1]))
+        for f in f_w:                                                           # e(lhs1, h) == e(pi, rhs2)
+            pr = f.result()
+            ok &= D(pr[0, 0]) == D(pr[1, 1])
+        return bool(ok)
 
 
 def verifier_key(ctx, curve, srs):

@@ -77,3 +77,17 @@ def test_rom_challenges_are_the_sha256_of_the_serialized_commitment():
     assert e == int.from_bytes(hashlib.sha256(b"entry_chal" + ser).digest(), "little") % r
     assert tr == int.from_bytes(hashlib.sha256(b"tr_chal" + ser).digest(), "little") % r
     assert e != tr and rom_challenges(IppCom(F, u, t), r) != (e, tr)
+
+
+def test_ippcom_lincomb_equals_the_operator_form():
+    from hekaton_system_amd.aggregation import IppCom
+    from hekaton_system_amd.gt import GtField
+    import random
+    F = GtField("bn254")
+    rnd = random.Random(3)
+    el = lambda: tuple(rnd.randrange(F.q) for _ in range(12))
+    a, b, c = IppCom(F, el(), el(), el()), IppCom(F, el(), el()), IppCom(F, el(), el())
+    k1, k2 = 0x1234567, 0x89abcdef0123
+    want = a + b * k1 + c * k2
+    got = IppCom.lincomb([(a, None), (b, k1), (c, k2)])
+    assert got == want and got.t == want.t and got.u == want.u and got.ip == want.ip
