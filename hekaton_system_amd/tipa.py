@@ -28,7 +28,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .aggregation import IPCommKey, IppCom, TIPPCommitment
+from .aggregation import IPCommKey, TIPPCommitment
 from .cp_groth16 import CURVE_PARAMS, FrCodec
 from .gt import GtField
 
