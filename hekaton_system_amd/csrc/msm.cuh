@@ -28,7 +28,10 @@
 namespace hk {
 
 constexpr int MSM_MAX_LEVELS = 16;
-constexpr u32 MSM_LVL_L = 16;          // entries per lane on levels >= 1: 6 levels for a full 2^18-lane level 0 (8: 10 levels)
+#ifndef HK_MSM_LVL_L
+#define HK_MSM_LVL_L 16
+#endif
+constexpr u32 MSM_LVL_L = HK_MSM_LVL_L;          // entries per lane on levels >= 1: 6 levels for a full 2^18-lane level 0 (8: 10 levels)
 constexpr int MSM_TAIL_THREADS = 256;  // levels whose lane count fits one workgroup run fused in k_msm_accum_tail
 constexpr int MSM_WSUM_THREADS = 256;
 constexpr int MSM_SORT_THREADS = 1024;
