@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the BLS12-381 secondary measurement (N = 1 only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing checks of the timed proofs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the post-timing aggregation of the last step's proofs")
     ap.add_argument("--witness-gen", action="store_true",
                     help="real-SHA configs only: generate every subcircuit's witness inside the step, on the GPU, from the "
                          "subcircuit's inputs (hk_wprog_run: the class's word program + column map, csrc/witness.cuh); the "
@@ -172,6 +173,12 @@ def plan_classes(args, rank, world, single_class):
     return n_total, shard, class_of
 
 
+def job_instance():
+    """The job's three public inputs (entry_chal, tr_chal, root): one triple for every subcircuit, as in the reference
+    (aggregation.rs:192-205 combines the proofs under ONE set of public inputs)."""
+    return [int.from_bytes(hashlib.sha256(b"hekaton bench public input %d" % k).digest()[:31], "little") for k in range(3)]
+
+
 def prepare_job_host(args, curve, rank, world, single_class=False, witnesses=None):
     """Host half of a Job (no device, no HIP): per proving-key class of the rank's shard, the trusted setup's scalar
     work and the assignments, in parallel worker processes.  Called BEFORE anything initialises the GPU."""
@@ -184,7 +191,7 @@ def prepare_job_host(args, curve, rank, world, single_class=False, witnesses=Non
         members = [i for i in shard if class_of[i] == rep]
         k = min(nw, len(members))
         seed = hashlib.sha256(b"HEKATON1 class %d" % rep).digest()
-        jobs.append((curve, args.config, rep, seed, [1000 * rep + j + 1 for j in range(k)], n_total))
+        jobs.append((curve, args.config, rep, seed, [1000 * rep + j + 1 for j in range(k)], n_total, job_instance()))
     t0 = time.time()
     out = {rep: (hs, assigns) for rep, hs, assigns in prepare_classes_host(jobs)}
     log("rank %d: %s host setup of %d proving-key class(es) %s in %.1f s" % (rank, curve, len(need), need, time.time() - t0))
@@ -249,6 +256,8 @@ class Job:
                 rank, curve, rep, len(members), len(zs), time.time() - t0))
         prepared["classes"] = None                   # the host copies are no longer needed
         self.circ = self.classes[self.main_class]["circ"]
+        from hekaton_system_amd.workload import SyntheticSubcircuit
+        self.synthetic = isinstance(self.circ, SyntheticSubcircuit)
         # which assignment a subcircuit uses: its position within its class, cycled
         self.assign_of = {}
         for rep, c in self.classes.items():
@@ -370,7 +379,10 @@ class Job:
         i = self.shard[-1]
         c = self.classes[self.class_of[i]]
         circ, td = c["circ"], c["td"]
-        circ.set_witness_seed(c["seeds"][self.assign_of[i]])
+        if self.synthetic:
+            circ.set_witness_seed(c["seeds"][self.assign_of[i]], job_instance())
+        else:
+            circ.set_witness_seed(c["seeds"][self.assign_of[i]])
         z_ints = circ.assignment_ints_current() if hasattr(circ, "assignment_ints_current") else circ.assignment_ints()
         A, B, C = c["matrices"]
         h_b, m = self.ctx.witness_map(A, B, C, circ.N_INST, circ.n_c, c["zs"][self.assign_of[i]], n_v=circ.n_v)
@@ -395,6 +407,72 @@ class Job:
             if c.get("wprog"):
                 c["wprog"].free()
         self.ctx.close()
+
+
+def end_to_end(job, use_dist, two_rounds_s):
+    """After the timed region, outside `value`: the rest of the job the reference runs once the proofs are in
+    (mpi-snark/src/coordinator.rs, distributed-prover/src/aggregation.rs:138-345) on the proofs of the LAST TIMED STEP -
+    super commitment, `agg_subcircuit_proofs` (IPP commitments, twisted vectors, 4 x 4 cross terms, TIPA prove) and the
+    verifier's TIPA check.  Its pairing-product assertion (aggregation.rs:265-269) holds only if EVERY timed proof
+    satisfies the Groth16 verifier equation under its class's verifying key, so this is also the check of all timed
+    proofs.  Key generation (TIPA SRS, AggProvingKey::new) is reported separately and not counted."""
+    import numpy as np
+    from hekaton_system_amd import aggregation as agg, tipa
+    from hekaton_system_amd.cp_groth16 import Proof
+    from hekaton_system_amd.merlin import Transcript
+    from hekaton_system_amd.workload import config_classes, representative_subcircuit
+    n = job.n_total
+    local = {rep: c["pk"].vk for rep, c in job.classes.items()}
+    if use_dist:
+        import torch.distributed as dist
+        parts = [None] * job.world
+        dist.all_gather_object(parts, local)
+        vk_of = {}
+        for d in parts:
+            vk_of.update(d)
+    else:
+        vk_of = local
+    if job.rank != 0:
+        return None
+    family, _n, _reps = config_classes(job.args.config)
+    cls = (lambda i: 1) if job.args.single_class else (lambda i: representative_subcircuit(family, n, i))
+    ctx, fc, r = job.ctx, job.fc, job.fc.r
+    g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
+    all0, all1 = job.last_records
+    coms = [np.asarray(rec[8:8 + g1b]) for rec in all0]
+    proofs = []
+    for i, rec in enumerate(all1):
+        a, b, c = rec[8:8 + g1b], rec[8 + g1b:8 + g1b + g2b], rec[8 + g1b + g2b:8 + 2 * g1b + g2b]
+        proofs.append(Proof(np.asarray(a), np.asarray(b), np.asarray(c), [coms[i]]))
+    rnd = lambda tag: int.from_bytes(hashlib.sha256(tag).digest(), "little") % r
+    t0 = time.time()
+    srs = tipa.setup(ctx, job.curve, n, rnd(b"tipa alpha"), rnd(b"tipa beta"))
+    t1 = time.time()
+    apk = agg.AggProvingKey(ctx, job.curve, srs.ck, [vk_of[cls(i)] for i in range(n)])
+    t2 = time.time()
+    tipp = tipa.Tipp(ctx, job.curve)
+    vk = tipa.verifier_key(ctx, job.curve, srs)
+    pub = job_instance()
+    res = {}
+    for attempt in ("warm", "timed"):
+        ta = time.time()
+        super_com = apk.com.commit_only_left(srs.ck, np.concatenate(coms))              # coordinator.rs:339
+        tb = time.time()
+        proof, inst = apk.agg_subcircuit_proofs(Transcript(b"hekaton-bench"), super_com, proofs, pub, srs, tipp=tipp, check=False)
+        tc = time.time()
+        ok = tipp.verify(vk, inst["commitment"], inst["output"], inst["twist"], proof)
+        td = time.time()
+        assert ok, "TIPA proof of the timed proofs rejected"
+        res = {"super_commitment_s": tb - ta, "aggregate_s": tc - tb, "verify_s": td - tc}
+    for rb in srs.resident.values():
+        rb.free()
+    res.update({"subcircuits": n, "two_rounds_s": two_rounds_s, "total_s": two_rounds_s + res["super_commitment_s"] + res["aggregate_s"],
+                "all_timed_proofs_pass_the_pairing_product_equation": True, "tipa_proof_verified": True,
+                "not_counted": {"tipa_setup_s": t1 - t0, "agg_key_s": t2 - t1},
+                "note": "two_rounds_s = one timed step (commit round, gather, prove round, gather); aggregation of that step's proofs "
+                        "measured once after the timed region (second of two runs); total_s = proving wall-clock of the job up to the "
+                        "aggregate proof"})
+    return res
 
 
 def timed_run(job, steps, warmup, barrier):
@@ -529,6 +607,16 @@ def main():
         checks["seconds"] = time.time() - t0
         log("rank %d: timed proofs verified: %s" % (rank, checks))
     proofs = world * args.subcircuits * args.steps
+    e2e = None
+    n_tot = world * args.subcircuits
+    if not args.no_e2e and job.synthetic and n_tot & (n_tot - 1) == 0:
+        try:
+            e2e = end_to_end(job, use_dist, dt / args.steps)          # every rank: the verifying keys are gathered
+            if rank == 0:
+                log("end to end: %s" % {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e2e.items() if k != "note"})
+        except Exception as e:       # noqa: BLE001
+            log("rank %d: end-to-end leg failed: %r" % (rank, e))
+            e2e = {"error": repr(e)}
     if rank == 0:
         m, roof = roofline_of(job, args.curve)
         nprov = max(1, len(job.accum_ms))
@@ -550,6 +638,7 @@ def main():
             "per_rank_proofs_per_s": per_rank, "gather_ms_per_step": gather_ms,
             "witness_gen_ms_per_step": (job.wg_s / args.steps * 1e3) if args.witness_gen else None,
             "timed_proofs_check": checks,
+            "end_to_end": e2e,
             "phase_ms_per_proof": {k: v / nprov for k, v in job.phase.items() if k.endswith("_ms")},
         }
         if want_cpu:

@@ -147,9 +147,12 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
     def total_num_stages(self):
         return 2
 
-    def set_witness_seed(self, seed):
-        """Selects which subcircuit instance (which assignment) the next commit/prove is for."""
+    def set_witness_seed(self, seed, instance=None):
+        """Selects which subcircuit instance (which assignment) the next commit/prove is for.  `instance`: the job's
+        public inputs (entry_chal, tr_chal, root - the same for every subcircuit of a job, which is what lets the
+        aggregator combine the proofs, aggregation.rs:192-205); None = drawn from the seed."""
         self.seed = seed
+        self.instance = None if instance is None else [int(v) % self.r for v in instance]
         self._z = None
 
     def generate_constraints(self, stage, cs):
@@ -327,6 +330,8 @@ class SyntheticSubcircuit(MultiStageConstraintSynthesizer):
         z[0] = 1
         for j in range(1, ni):
             z[j] = prng.randrange(r)
+        if getattr(self, "instance", None) is not None:
+            z[1:ni] = self.instance
         for j in np.nonzero(~self.is_bit_var)[0].tolist():
             z[ni + j] = prng.randrange(r)
         for j, v in zip(free_bits.tolist(), bits[free_bits].tolist()):
@@ -416,16 +421,21 @@ def prepare_class_host(job):
     """Worker-process half of a benchmark / test setup: builds one proving-key class's circuit, runs the host half of
     the trusted setup (`cp_groth16.setup_host`: toxic waste, QAP evaluation, scalar layout) and generates the
     assignments of `witness_seeds`.  Pure Python / numpy, no device: safe to run in a spawned process pool BEFORE the
-    parent initialises HIP.  job = (curve, config name, class representative, setup seed bytes, [witness seeds]);
+    parent initialises HIP.  job = (curve, config name, class representative, setup seed bytes, [witness seeds]
+    [, n_total [, job-wide public inputs]]);
     returns (class_rep, HostSetup, [(seed, full assignment bytes, stage-0 witness bytes)])."""
     from .cp_groth16 import SeededRng, setup_host
     curve, name, rep, seed, witness_seeds = job[:5]
     n_total = job[5] if len(job) > 5 else None
+    instance = job[6] if len(job) > 6 else None
     circ = make_config(curve, name, rep, n_total)
     hs = setup_host(circ, curve, SeededRng(seed))
     assigns = []
     for ws in witness_seeds:
-        circ.set_witness_seed(ws)
+        if instance is not None and isinstance(circ, SyntheticSubcircuit):
+            circ.set_witness_seed(ws, instance)
+        else:
+            circ.set_witness_seed(ws)
         assigns.append((ws, circ.full_assignment_bytes(), circ.stage0_witness_bytes()))
     return rep, hs, assigns
 

@@ -5,7 +5,7 @@
 set -o pipefail
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 O=gpurun_out/prof_r02; mkdir -p $O
-B="--no-cpu-baseline --no-secondary"
+B="--no-cpu-baseline --no-secondary --no-e2e"
 echo "== bench (default line)"; timeout -k 10 500 python bench.py --steps 6 --warmup 2 > $O/bench.json 2> $O/bench.err || exit 1
 echo "== rocprof default bench"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o run -- python3 bench.py $B --steps 2 --warmup 1 > $O/bench_under_rocprof_default.json 2> $O/rocprof_default.err || exit 1
