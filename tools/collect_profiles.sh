@@ -6,7 +6,9 @@ set -o pipefail
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 O=gpurun_out/prof_r02; mkdir -p $O
 B="--no-cpu-baseline --no-secondary --no-e2e"
-echo "== bench (default line)"; timeout -k 10 500 python bench.py --steps 6 --warmup 2 > $O/bench.json 2> $O/bench.err || exit 1
+echo "== bench with no flags (wall time of the default invocation)"; t0=$(date +%s); timeout -k 10 600 python bench.py > $O/bench_noflags.json 2> $O/bench_noflags.err || exit 1
+echo "python bench.py (no flags) wall time: $(( $(date +%s) - t0 )) s" | tee $O/bench_wall.txt
+echo "== bench (profile line: 6 timed steps)"; timeout -k 10 600 python bench.py --steps 6 --warmup 2 > $O/bench.json 2> $O/bench.err || exit 1
 echo "== rocprof default bench"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o run -- python3 bench.py $B --steps 2 --warmup 1 > $O/bench_under_rocprof_default.json 2> $O/rocprof_default.err || exit 1
 echo "== rocprof serial streams"
@@ -17,7 +19,10 @@ echo "== pmc write"
 HK_SERIAL_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py $B --single-class --steps 1 --warmup 0 --subcircuits 2 --threads 1 --no-verify > /dev/null 2> $O/pmc_write.err || exit 1
 echo "== other configs"
 for c in big-merkle-512x64 vm-1024x1024 vkd-256 big-merkle-4x1; do
-  timeout -k 10 500 python bench.py $B --config $c --steps 2 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err || echo "config $c failed"
+  timeout -k 10 500 python bench.py --no-cpu-baseline --no-secondary --config $c --steps 2 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err || echo "config $c failed"
 done
+echo "== real SHA-256 subcircuits"
+timeout -k 10 500 python bench.py $B --config big-merkle-sha-64x32 --steps 3 --warmup 1 > $O/bench_big-merkle-sha-64x32.json 2> $O/bench_sha.err || echo "sha config failed"
+timeout -k 10 500 python bench.py $B --config big-merkle-sha-64x32 --witness-gen --steps 3 --warmup 1 > $O/bench_big-merkle-sha-64x32_witness_gen.json 2> $O/bench_sha_wg.err || echo "sha witness-gen config failed"
 find $O -name "*.csv" | head -30
 echo done
