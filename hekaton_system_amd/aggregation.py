@@ -118,12 +118,10 @@ class IppCom:
 
 
 def rom_challenges(super_com, r_mod):
-    """(entry_chal, tr_chal) of a ROM job: SHA-256 of a context string and the serialized commitment to all stage-0
-    commitments, reduced little-endian mod r (`RomRunningEvaluation::new`,
-    distributed-prover/src/transcript/rom_transcript.rs:42-75)."""
-    import hashlib
-    com_bytes = super_com.serialize_uncompressed()
-    return tuple(int.from_bytes(hashlib.sha256(tag + com_bytes).digest(), "little") % r_mod for tag in (b"entry_chal", b"tr_chal"))
+    """(entry_chal, tr_chal) of a ROM job (`RomRunningEvaluation::new`, rom_transcript.rs:42-75; the whole running
+    evaluation object is transcript.RunningEvaluation)."""
+    from .transcript import ROM, RunningEvaluation
+    return RunningEvaluation.new(ROM, super_com, r_mod).challenges
 
 
 class TIPPCommitment:

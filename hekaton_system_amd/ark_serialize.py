@@ -442,15 +442,32 @@ class ArkCodec:
         return v
 
     def _write_entry(self, w, e):
+        """`TranscriptEntry` (transcript/mod.rs:216-233): tag 0 = Rom (addr u64, val), tag 1 = Ram (addr, val, i as
+        Vec<bool>, read).  ROM entries may be plain (addr, val) tuples."""
+        from .transcript import RamTranscriptEntry, RomTranscriptEntry
+        if isinstance(e, RamTranscriptEntry):
+            w.put(b"\x01" + e.to_wire(self.frb))
+            return
+        if isinstance(e, RomTranscriptEntry):
+            e = (e.addr, e.val)
         w.put(b"\x00")
         w.u64(e[0])
         w.put(self._fr_wire(e[1]))
 
     def _read_entry(self, r):
         tag = bytes(r.take(1))[0]
-        if tag != 0:
-            raise SerializationError("InvalidData: only ROM transcript entries (tag 0) are supported, got %d" % tag)
-        return (r.u64(), self._fr_read(r))
+        if tag == 0:
+            return (r.u64(), self._fr_read(r))
+        if tag == 1:
+            from .transcript import RamTranscriptEntry
+            addr, val = r.u64(), self._fr_read(r)
+            if r.u64() != 32:
+                raise SerializationError("InvalidData: Unsigned32 is 32 bools")
+            raw = bytes(r.take(33))
+            if any(b > 1 for b in raw):
+                raise SerializationError("InvalidData: bool byte > 1")
+            return RamTranscriptEntry(addr, val, sum(int(b) << k for k, b in enumerate(raw[:32])), bool(raw[32]))
+        raise SerializationError("InvalidData: TranscriptEntry tag %d" % tag)
 
     def stage0_request_to_wire(self, req):
         """Stage0RequestRef (coordinator.rs:229-249): subcircuit_idx | Vec<TranscriptEntry> time | Vec<..> addr."""
