@@ -318,7 +318,7 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
             u32 g = (e & 0x7fffffffu) >> p.gshift;
             u32 i = e & ((1u << p.gshift) - 1u);
             v_n = i >= idx_off && i - idx_off < n_bases;
-            P_n = ld_vec(&bases[v_n ? (size_t)g * n_bases + (i - idx_off) : 0]);
+            if (v_n) P_n = ld_vec(&bases[(size_t)g * n_bases + (i - idx_off)]);     // never touches an empty table
         };
         if (pos < end) request_row(sorted[pos]);
         if (pos + 1 < end) e_nn = sorted[pos + 1];

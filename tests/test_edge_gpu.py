@@ -80,6 +80,37 @@ def test_prove_with_empty_stage0_and_bad_lengths(ctx_bn254):
     assert e.value.status == capi.HK_ERR_LEN
 
 
+def test_prove_with_empty_last_stage(ctx_bn254):
+    """The mirror case: every witness is committed in stage 0 and the last stage allocates none, so the L query of
+    prover.rs:111-118 is an MSM over ZERO bases (its table is empty: the accumulate loop must not touch it)."""
+    cp = BN254
+    cd = Codec(cp)
+    cs = groth16.R1CS(cp.r)
+    cs.begin_stage()
+    w = cs.alloc_witness(36)
+    v = cs.alloc_witness(6)
+    cs.end_stage()
+    cs.begin_stage()
+    x = cs.alloc_instance(6)
+    cs.enforce([(1, x)], [(1, v)], [(1, w)])
+    cs.enforce([(1, v)], [(1, "one")], [(1, x)])
+    cs.end_stage()
+    assert cs.is_satisfied()
+    pk, td = groth16.generate_parameters(cp, cs, 3, 5, 7, [11, 13], 17, 2, 3)
+    assert len(pk.ck.deltas_abc_g[-1]) == 0
+    dpk = pk_upload_from_oracle(ctx_bn254, cd, pk, cs)
+    kappa, r_, s_ = 31, 32, 33
+    com = cd.g1_from(dpk.commit(0, cd.fr_vec_mont([36, 6]), cd.fr_vec_mont([kappa])))
+    assert com == groth16.commit(cp, cs, pk, 0, kappa)
+    a, b, c = dpk.prove(cd.fr_vec_mont(cs.full_assignment()), cd.fr_vec_mont([r_]), cd.fr_vec_mont([s_]),
+                        cd.fr_vec_mont([kappa]))
+    proof = groth16.Proof(cd.g1_from(a), cd.g2_from(b), cd.g1_from(c), [com])
+    assert groth16.verify_proof_trapdoor(cp, cs, pk, td, proof, [kappa], r_, s_)
+    want = groth16.prove(cp, cs, pk, [com], [kappa], r_, s_)
+    assert (proof.a, proof.b, proof.c) == (want.a, want.b, want.c)
+    dpk.free()
+
+
 def test_two_keys_resident_at_once(ctx_bn254):
     """Several proving-key classes live on the device together (big-merkle has 5, tree_hash_circuit.rs:192-216)."""
     cp = BN254
