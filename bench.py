@@ -47,8 +47,8 @@ def log(*a):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="big-merkle-64x32",
                     help="workload (hekaton_system_amd/workload.py CONFIGS); default = BASELINE configs[1]")
     ap.add_argument("--curve", default="bn254", help="bn254 is what the reference instantiates (SURVEY F1)")
