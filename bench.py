@@ -502,7 +502,9 @@ def roofline_of(job, curve):
     g1 = ctx.g1_bytes
     n1 = circ.n_v - circ.N_INST - circ.n0
     fq_limbs = ctx.fq_bytes // 4
-    nwin = (ctx.fr_bytes * 8 + 1 + 15) // 16 if curve == "bls12_381" else 16      # ceil((bits+2)/16): 16 / 17
+    # signed 16-bit windows of the H query (csrc/msm.cuh msm_num_windows): 16 on both curves - BLS12-381's r = 0.906 * 2^255
+    # leaves room for the "+2^15 per window" constant inside 256 bits, so there is no 17th digit
+    nwin = 16
     terms = [m - 1, circ.n_v - 1, circ.n_v - 1, n1, circ.n0]
     alg_bytes = sum(terms) * (32 + g1) / len(terms)
     avg_ms = float(np.sum(job.accum_ms) / max(1, np.sum(job.accum_n))) if job.accum_ms else float("nan")

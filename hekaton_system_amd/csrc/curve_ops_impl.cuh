@@ -66,7 +66,7 @@ struct Ops {
         Lane* L = g.lane;
         if (!L) return HK_ERR_DEVICE;
         u32 c = msm_pick_c_plain(n, C::FR_BITS);
-        MsmPlan p = msm_make_plan((u32)n, C::FR_BITS, c, 0xffffffffu, ctx->max_lanes0);
+        MsmPlan p = msm_make_plan((u32)n, C::FR_BITS, c, 0xffffffffu, ctx->max_lanes0, C::Fr::Params::MOD, C::Fr::Params::N);
         size_t need = al256(n * sizeof(Fr)) + al256(n * sizeof(Affine<F>)) + msm_sort_bytes(p) +
                       msm_run_bytes<F>(p) + al256(sizeof(XYZZ<F>)) + al256(sizeof(Affine<F>)) + 4096;
         HK_TRY(L->reserve(need));

@@ -607,14 +607,47 @@ inline void msm_set_lanes(MsmPlan& p, u32 max_lanes0) {
     p.n_levels = k + 1;
 }
 
-inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0) {
+// Number of signed c-bit windows: the digits of s are read from s' = s + kconst_W (kconst_W = sum_{w<W} 2^(cw+c-1)), so W
+// windows suffice iff (r - 1) + kconst_W < 2^(cW).  ceil((bits + 2) / c) always does; one window fewer does whenever the
+// modulus leaves the room - BLS12-381's r = 0.906 * 2^255 at c = 16: 16 windows, not 17 (the 17th digit was always zero:
+// no adds, but a 17th shift table per key and a 17th digit in every sort pass).
+inline u32 msm_num_windows(u32 fr_bits, u32 c, const u32* mod, int n_limbs) {
+    u32 W = (fr_bits + 2 + c - 1) / c;
+    if (!mod || W < 2 || n_limbs > 8) return W;
+    u32 Wt = W - 1;
+    if (c * Wt < fr_bits || c * Wt > 288) return W;
+    u32 sum[10] = {0}, kc[10] = {0};
+    for (u32 w = 0; w < Wt; w++) {
+        u32 bit = c * w + c - 1;
+        kc[bit >> 5] |= 1u << (bit & 31);
+    }
+    u64 carry = 0;
+    for (int i = 0; i < 10; i++) {                                  // sum = r + kconst_Wt  (= (r - 1) + kconst + 1)
+        carry += (u64)(i < n_limbs ? mod[i] : 0) + kc[i];
+        sum[i] = (u32)carry;
+        carry >>= 32;
+    }
+    // sum <= 2^(c Wt)  <=>  every bit above c*Wt is clear, or sum == 2^(c Wt) exactly
+    u32 top = c * Wt;
+    bool above = false, below = false;
+    for (u32 b = 0; b < 320; b++) {
+        bool set = (sum[b >> 5] >> (b & 31)) & 1;
+        if (b > top && set) above = true;
+        if (b < top && set) below = true;
+    }
+    bool at = (sum[top >> 5] >> (top & 31)) & 1;
+    bool ok = !above && (!at || !below);
+    return ok ? Wt : W;
+}
+
+inline MsmPlan msm_make_plan(u32 n, u32 fr_bits, u32 c, u32 WP, u32 max_lanes0, const u32* mod = nullptr, int n_limbs = 0) {
     MsmPlan p;
     p.n = n;
     p.gshift = 1;
     while (((u64)1 << p.gshift) < n) p.gshift++;
     p.c = c;
     p.B = 1u << (c - 1);
-    p.W = (fr_bits + 2 + c - 1) / c;
+    p.W = msm_num_windows(fr_bits, c, mod, n_limbs);
     if (WP > p.W) WP = p.W;
     p.WP = WP;
     p.F = (p.W + WP - 1) / WP;

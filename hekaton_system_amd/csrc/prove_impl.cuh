@@ -489,7 +489,7 @@ hk_status Ops<C>::pk_upload(hk_ctx* ctx, const hk_pk_desc* d, hk_pk** out) {
     auto make_plan = [&](size_t n) {
         u32 c = msm_pick_c_tables(n, C::FR_BITS);
         if (WP > 1) { while (c > 5 && ((u64)WP << (c - 1)) > (u64)MSM_LDS_COUNTERS) c--; }
-        return msm_make_plan((u32)n, C::FR_BITS, c, WP, ctx->max_lanes0);
+        return msm_make_plan((u32)n, C::FR_BITS, c, WP, ctx->max_lanes0, C::Fr::Params::MOD, C::Fr::Params::N);
     };
     pk->plan_z = make_plan(pk->n_ext);
     const MsmPlan& pz = pk->plan_z;
@@ -694,7 +694,7 @@ hk_status Ops<C>::bases_upload(hk_ctx* ctx, int group, const void* bases, size_t
     b->n = (u32)n;
     hk_bases* h = new hk_bases{ctx->ops, ctx, b};
     if (n == 0) { *out = h; return HK_OK; }
-    b->plan = msm_make_plan((u32)n, C::FR_BITS, msm_pick_c_tables(n, C::FR_BITS), 1u, ctx->max_lanes0);
+    b->plan = msm_make_plan((u32)n, C::FR_BITS, msm_pick_c_tables(n, C::FR_BITS), 1u, ctx->max_lanes0, C::Fr::Params::MOD, C::Fr::Params::N);
     auto build = [&](auto ftag) -> hk_status {
         typedef decltype(ftag) F;
         size_t bytes = (size_t)b->plan.F * n * sizeof(Affine<F>);
