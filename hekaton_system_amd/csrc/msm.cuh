@@ -23,6 +23,7 @@
 // group then share one bucket set and the serial Horner tail shrinks from ~254 doublings to
 // c*(WP-1) (zero when WP == 1).
 #pragma once
+#include <cstdlib>
 #include "ec.cuh"
 
 namespace hk {

@@ -2,6 +2,7 @@
 // run can be unit-tested against the oracle without a GPU.  Test-only; never part of libhekaton.
 #include "../../hekaton_system_amd/csrc/ec.cuh"
 #include "../../hekaton_system_amd/csrc/pairing.cuh"
+#include "../../hekaton_system_amd/csrc/msm.cuh"
 #include <string.h>
 using namespace hk;
 
@@ -100,5 +101,13 @@ void shim_group_op(int group, int op, const void* a, const void* b, void* out) {
         case 2: group_op<Fp<Bls381FqP>>(op, a, b, out); break;
         case 3: group_op<Fp2<Bls381FqP>>(op, a, b, out); break;
     }
+}
+// the MSM schedule (host code of csrc/msm.cuh): windows, buckets, level lanes of a plan
+// out[0..5] = W, F, NB, n_levels, T[0], chunk; curve: 0 bn254, 1 bls12-381
+void shim_msm_plan(int curve, unsigned n, unsigned c, unsigned WP, unsigned max_lanes0, unsigned* out) {
+    MsmPlan p = curve == 0 ? msm_make_plan(n, 254, c, WP, max_lanes0, Bn254FrP::MOD, Bn254FrP::N)
+                           : msm_make_plan(n, 255, c, WP, max_lanes0, Bls381FrP::MOD, Bls381FrP::N);
+    out[0] = p.W; out[1] = p.F; out[2] = p.NB; out[3] = p.n_levels; out[4] = p.T[0]; out[5] = p.chunk;
+    for (int i = 0; i < 10; i++) out[6 + i] = p.kconst[i];
 }
 }

@@ -102,3 +102,40 @@ def test_product_field_and_curve_arithmetic_vs_golden(shim):
                 assert gop(ids[cname][key], 0, p, q, len(p)) == c["add"]       # mixed add
                 assert gop(ids[cname][key], 1, p, q, len(p)) == c["add"]       # full XYZZ add
                 assert gop(ids[cname][key], 0, p, p, len(p)) == c["dbl_p"]     # P + P corner
+
+
+def test_msm_window_count_is_the_smallest_that_holds_every_scalar(tmp_path_factory):
+    """csrc/msm.cuh `msm_num_windows` (host code, compiled here with g++): with the signed-digit recoding
+    s' = s + sum_{w<W} 2^(cw+c-1), W windows are enough iff (r - 1) + that constant < 2^(cW).  The plan must pick the
+    SMALLEST such W that is >= the always-sufficient ceil((bits+2)/c) - 1, for every window size either curve can get:
+    16 windows at c = 16 on both (BLS12-381's 17th digit would always be zero), and never a W that lets s' overflow."""
+    import ctypes
+    import subprocess
+    from oracle.pyref.params import CURVES
+    out = str(tmp_path_factory.mktemp("shim") / "field_shim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out,
+                           os.path.join(ROOT, "tests", "host_shim", "field_shim.cpp")])
+    lib = ctypes.CDLL(out)
+    buf = (ctypes.c_uint * 16)()
+    for cid, name, bits in ((0, "bn254", 254), (1, "bls12_381", 255)):
+        r = CURVES[name].r
+        assert r.bit_length() == bits
+        for c in range(3, 17):
+            lib.shim_msm_plan(cid, 1 << 20, c, 1, 1 << 18, buf)
+            W = buf[0]
+            kconst = sum(buf[6 + i] << (32 * i) for i in range(10))
+            assert kconst == sum(1 << (c * w + c - 1) for w in range(W))
+            fits = lambda w: (r - 1) + sum(1 << (c * k + c - 1) for k in range(w)) < (1 << (c * w))
+            assert fits(W), (name, c, W)
+            upper = (bits + 2 + c - 1) // c
+            assert W in (upper, upper - 1)
+            if W == upper:
+                assert not fits(upper - 1), (name, c, "one window fewer would have been enough")
+            # every digit of the extreme scalars is in range and the top window never carries out
+            for s in (0, 1, r - 1, r - 2, (1 << (bits - 1)) - 1):
+                sp = s + kconst
+                assert sp >> (c * W) == 0
+                digs = [((sp >> (c * w)) & ((1 << c) - 1)) - (1 << (c - 1)) for w in range(W)]
+                assert sum(d << (c * w) for w, d in enumerate(digs)) == s
+        lib.shim_msm_plan(cid, 1 << 21, 16, 1, 1 << 18, buf)
+        assert buf[0] == 16 and buf[1] == 16 and buf[2] == 1 << 15
