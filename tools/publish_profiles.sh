@@ -1,0 +1,25 @@
+#!/bin/bash
+# Copies what tools/collect_profiles.sh left under gpurun_out/prof_r02 into profiles/ under their tracked names.
+set -e
+cd "$(dirname "$0")/.."
+O=gpurun_out/prof_r02; P=profiles; R=${1:-r02}
+cp $O/bench.json $P/${R}_bench.json
+cp $O/bench_noflags.json $P/${R}_bench_no_flags.json
+cp $O/bench_wall.txt $P/${R}_bench_wall_time.txt
+cp $O/stats_default/run_kernel_stats.csv $P/${R}_kernel_stats_default_bench.csv
+cp $O/bench_under_rocprof_default.json $P/${R}_bench_under_rocprof_default.json
+cp $O/stats_serial/run_kernel_stats.csv $P/${R}_kernel_stats_serial_streams.csv
+cp $O/bench_under_rocprof_serial.json $P/${R}_bench_under_rocprof_serial_streams.json
+for c in big-merkle-512x64 vm-1024x1024 vkd-256 big-merkle-4x1 big-merkle-sha-64x32 big-merkle-sha-64x32_witness_gen; do
+  [ -s $O/bench_$c.json ] && cp $O/bench_$c.json $P/${R}_bench_$c.json
+done
+python3 tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv $P/${R}_pmc_accum0.json > /dev/null
+python3 - <<PY
+import json
+d = json.load(open("$P/${R}_pmc_accum0.json"))
+out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, tools/pmc_traffic.py); per-launch averages of k_msm_accum0<Fp<...FqP>>, raw counter values (random 64-B gathers: no x2 calibration, see DESIGN.md section 4)",
+       "big-merkle-64x32/bn254": {"FETCH_SIZE_KiB_avg": d["FETCH_SIZE_KiB_avg"], "WRITE_SIZE_KiB_avg": d["WRITE_SIZE_KiB_avg"],
+                                  "collected": "profiles/${R}_pmc_accum0.json"}}
+json.dump(out, open("$P/pmc_accum0.json", "w"), indent=1)
+print("traffic per launch: %.1f MB" % ((d["FETCH_SIZE_KiB_avg"] + d["WRITE_SIZE_KiB_avg"]) * 1024 / 1e6))
+PY
