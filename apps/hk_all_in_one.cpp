@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     std::string job = argv[1], out = argv[2];
-    unsigned threads = 18, steps = 1, warmup = 0;
+    unsigned threads = 8, steps = 1, warmup = 0;
     int device = 0;
     bool host_inputs = false;
     for (int i = 3; i < argc; i++) {

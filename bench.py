@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--curve", default="bn254", help="bn254 is what the reference instantiates (SURVEY F1)")
     ap.add_argument("--subcircuits", type=int, default=64,
                     help="subcircuits per GPU per step (default: the 64 subcircuits of BASELINE configs[1])")
-    ap.add_argument("--threads", type=int, default=18, help="host threads (= GPU lanes) proving concurrently")
+    ap.add_argument("--threads", type=int, default=8, help="host threads (= GPU lanes) proving concurrently")
     ap.add_argument("--witnesses", type=int, default=4, help="distinct assignments per proving-key class")
     ap.add_argument("--single-class", action="store_true",
                     help="prove every subcircuit against ONE proving-key class (debug; the default holds every class "
@@ -551,8 +551,10 @@ def roofline_of(job, curve):
 
 def main():
     args = parse()
-    # one hardware queue per lane; before anything imports the binding or touches HIP
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.threads))
+    # before anything imports the binding or touches HIP: with one stream per lane (HK_SERIAL_STREAMS=1, the experiment of
+    # DESIGN.md section 5) every lane gets its own hardware queue; the default forked form keeps the binding's 20
+    if os.environ.get("HK_SERIAL_STREAMS"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.threads))
     os.environ.setdefault("HK_MAX_LANES", str(max(args.threads, 8)))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))                     # before any HIP call

@@ -8,11 +8,11 @@ import os
 
 import numpy as np
 
-# every lane (= host thread proving at the moment) submits on its own stream: one hardware queue per lane instead of
-# the runtime's default of 4 shared ones (must be set before the HIP runtime initialises; harmless if the user set it).
-# Best = the number of threads that prove concurrently (bench.py exports its --threads before importing this module);
-# 18 is bench.py's default.  Measured in DESIGN.md section 5; hk_ctx_create exports the same default for other hosts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "18")
+# hk_prove forks four side streams per lane; let the runtime map them onto more hardware queues than
+# its default of 4 (must be set before the HIP runtime initialises; harmless if the user set it).
+# Measured with 8 proofs in flight (apps/hk_all_in_one): 8 queues 89 proofs/s, 16: 121-122,
+# 20-22: 123-125, 24 and more: 114-116 - hk_ctx_create exports the same value for hosts that do not come through here
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HK_LIB") or os.path.join(_HERE, "lib", "libhekaton.so")    # HK_LIB: experiment builds

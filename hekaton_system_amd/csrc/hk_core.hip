@@ -109,12 +109,12 @@ hk_status hk_ctx_create(hk_curve curve, int device_id, hk_ctx** out) {
     if (!out) return HK_ERR_ARG;
     *out = nullptr;
     if (curve != HK_BN254 && curve != HK_BLS12_381) return HK_ERR_ARG;
-    // Every lane (= host thread proving at the moment) submits on its own stream; give each its own hardware queue
-    // instead of the runtime's default of 4 shared ones (18 lanes: 4 queues 90 proofs/s, queues = lanes 125-129, more
-    // queues than lanes 115-120).  Read when the HIP runtime initialises, so this only takes effect
-    // if no HIP call was made before the first hk_ctx_create (a host that initialises HIP earlier, or runs another
-    // number of threads, exports it itself: INTEGRATION.md); never overrides a value the user set.
-    setenv("GPU_MAX_HW_QUEUES", "18", 0);
+    // hk_prove forks four side streams per lane and several lanes run at once: let the runtime map them onto more
+    // hardware queues than its default of 4 (8 proofs in flight: 4 queues 90 proofs/s, 16: 121, 20-22: 124, 24+: 115;
+    // DESIGN.md section 5).  Read when the HIP runtime initialises, so this only takes effect if no HIP call was made
+    // before the first hk_ctx_create (a host that initialises HIP earlier exports it itself); never
+    // overrides a value the user set.
+    setenv("GPU_MAX_HW_QUEUES", "20", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void)hipGetLastError();

@@ -135,7 +135,7 @@ struct hk_ctx {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<hk::Lane*> lanes;
-    size_t max_lanes = 24;          // concurrent calls beyond this wait for a lane (HK_MAX_LANES)
+    size_t max_lanes = 8;           // concurrent calls beyond this wait for a lane (HK_MAX_LANES)
     hk::NttTables* ntt = nullptr;
     hk_timings last;
     uint32_t max_lanes0 = 262144;   // level-0 accumulate lanes: 4 waves/SIMD x 1024 SIMDs x 64

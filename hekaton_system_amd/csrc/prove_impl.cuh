@@ -1282,16 +1282,17 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     Affine<Fq2>* ob = L->alloc_n<Affine<Fq2>>(1);
     Fr* abc = L->alloc_n<Fr>(3 * m);
     if (!res1 || !res2 || !oa || !ob || !abc) return HK_ERR_NOMEM;
-    // The five queries are independent once their scalars exist.  Default: ONE stream per lane - a worker keeps many
-    // proofs in flight (18 lanes in bench.py), the kernels of other proofs fill the latency-bound tails of this one,
-    // and with one stream per lane every lane owns a hardware queue (GPU_MAX_HW_QUEUES = lanes).  Measured against the
-    // forked form with 8 lanes: big-merkle-64x32 124 -> 124-128 proofs/s, BLS12-381 72 -> 73,
-    // vkd-256 442 -> 517, big-merkle-4x1 486 -> 670.  HK_FORK_STREAMS=1 forks four side streams instead, which is what a
-    // caller proving ONE subcircuit at a time wants (14 ms instead of ~20 per proof):
+    // Fork: the five queries are independent once their scalars exist.  Side streams let the
+    // latency-bound tails (segmented levels, bucket reduction) of one query hide under the
+    // throughput-bound accumulation of another.
     //   main  : sort(z) -> A
     //   aux0  : B1      aux1 : B2 (G2)      aux2 : L      aux3 : witness map -> sort(h) -> H
+    // HK_SERIAL_STREAMS=1 keeps everything on the lane's own stream: clean per-kernel times for profiling, and - with
+    // 18 lanes and GPU_MAX_HW_QUEUES=18, one hardware queue per lane - the faster form for small circuits (DESIGN.md
+    // section 5).  Not the default: 18 concurrent G2 tail kernels (2-3 KB of scratch per lane each) once exhausted the
+    // runtime's scratch pool on BLS12-381 and the process aborted (HSA_STATUS_ERROR_OUT_OF_RESOURCES).
     hipStream_t axs[4] = {L->aux[0], L->aux[1], L->aux[2], L->aux[3]};
-    static const bool serial = getenv("HK_FORK_STREAMS") == nullptr || getenv("HK_SERIAL_STREAMS") != nullptr;
+    static const bool serial = getenv("HK_SERIAL_STREAMS") != nullptr;
     if (serial) for (auto& a : axs) a = s;
     hipStream_t* ax = axs;
     // Every exit between the fork and the join - an HK_TRY / HK_HIP return included - must leave no side stream
