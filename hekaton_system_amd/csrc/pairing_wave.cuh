@@ -20,14 +20,16 @@ template <class P> struct WaveTab;
 #define HK_DEFINE_WAVETAB(FQP, PRE)                                                                      \
     static __device__ const unsigned char PRE##_pre_cnt[54] = PRE##_PRE_CNT;                             \
     static __device__ const unsigned char PRE##_pre_idx[54][8] = PRE##_PRE_IDX;                          \
-    static __device__ const unsigned char PRE##_post[48][PRE##_POST_LEN] = PRE##_POST;                   \
+    static __device__ const unsigned char PRE##_postf[48][PRE##_POSTF_LEN] = PRE##_POSTF;                \
     static __device__ const u32 PRE##_frob[3][6][2][FQP::N] = PRE##_FROB;                                \
     template <> struct WaveTab<FQP> {                                                                    \
         static constexpr int NLEVELS = PRE##_NLEVELS;                                                    \
-        static constexpr int POST_LEN = PRE##_POST_LEN;                                                  \
+        static constexpr int POSTF_LEN = PRE##_POSTF_LEN;                                                \
+        static constexpr int n_add(int l) { constexpr int t[PRE##_NLEVELS] = PRE##_POSTF_ADD; return t[l]; } \
+        static constexpr int n_sub(int l) { constexpr int t[PRE##_NLEVELS] = PRE##_POSTF_SUB; return t[l]; } \
         static __device__ __forceinline__ u32 pre_cnt(u32 l) { return PRE##_pre_cnt[l]; }               \
         static __device__ __forceinline__ const unsigned char* pre_idx(u32 l) { return PRE##_pre_idx[l]; } \
-        static __device__ __forceinline__ const unsigned char* post(u32 l) { return PRE##_post[l]; }     \
+        static __device__ __forceinline__ const unsigned char* postf(u32 l) { return PRE##_postf[l]; }   \
         static __device__ __forceinline__ const u32* frob(int k, u32 j, u32 c) { return PRE##_frob[k - 1][j][c]; } \
     };
 HK_DEFINE_WAVETAB(Bn254FqP, HK_BN254_WV)
@@ -35,11 +37,14 @@ HK_DEFINE_WAVETAB(Bls381FqP, HK_BLS12_381_WV)
 
 constexpr int WV_SLOT = 13;            // Fq per value: 12 coefficients + one zero
 
-// LDS work area of one wave
+// LDS work area of one wave.  prod[54..63] stay zero: the fixed-length recombination lists are padded with slot 54.
+// The lane's rows of the operand / recombination tables are copied here once per kernel (WaveF12::init).
 template <class P>
-struct WaveArea {
-    Fp<P> prod[54];
+struct alignas(16) WaveArea {
+    Fp<P> prod[64];
     Fp<P> part[48];
+    alignas(8) unsigned char pre_idx[54][8];
+    alignas(4) unsigned char postf[48][WaveTab<P>::POSTF_LEN];
 };
 
 template <class P>
@@ -49,33 +54,50 @@ struct WaveF12 {
 
     static __device__ __forceinline__ void sync() { __syncthreads(); }
 
-    // dst = a * b   (dst may alias a or b)
+    // once per kernel, before the first product: this lane's table rows -> LDS, the padding products -> 0
+    static __device__ __forceinline__ void init(WaveArea<P>* w) {
+        u32 lane = threadIdx.x;
+        if (lane < 54) {
+            const unsigned char* ix = T::pre_idx(lane);
+            for (int j = 0; j < 8; j++) w->pre_idx[lane][j] = ix[j];
+        }
+        if (lane < 48) {
+            const unsigned char* ps = T::postf(lane);
+            for (int j = 0; j < T::POSTF_LEN; j++) w->postf[lane][j] = ps[j];
+        }
+        if (lane >= 54) w->prod[lane] = Fq::zero();
+        sync();
+    }
+
+    // dst = a * b   (dst may alias a or b).  Straight-line code: every lane sums 8 (zero-padded) coefficients per
+    // operand and, per bit level of the multipliers, a fixed number of products to add and to subtract (padded with a
+    // zero product) - the trip counts the SIMD ran anyway, without the ~60 dependent LDS round trips of parsing a list.
     static __device__ __noinline__ void mul(Fq* dst, const Fq* a, const Fq* b, WaveArea<P>* w) {
         u32 lane = threadIdx.x;
         if (lane < 54) {
-            u32 cnt = T::pre_cnt(lane);
-            const unsigned char* ix = T::pre_idx(lane);
-            Fq x = a[ix[0]], y = b[ix[0]];
-            for (u32 j = 1; j < cnt; j++) {
-                x = Fq::add(x, a[ix[j]]);
-                y = Fq::add(y, b[ix[j]]);
+            const u32* ixw = reinterpret_cast<const u32*>(w->pre_idx[lane]);
+            u32 i0 = ixw[0], i1 = ixw[1];
+            Fq x = a[i0 & 0xff], y = b[i0 & 0xff];
+            HK_UNROLL for (int j = 1; j < 8; j++) {
+                u32 ix = ((j < 4 ? i0 : i1) >> (8 * (j & 3))) & 0xff;
+                x = Fq::add(x, a[ix]);
+                y = Fq::add(y, b[ix]);
             }
             w->prod[lane] = Fq::mul(x, y);
         }
         sync();
         if (lane < 48) {
-            const unsigned char* s = T::post(lane);
+            u32 codes[T::POSTF_LEN / 4];
+            const u32* row = reinterpret_cast<const u32*>(w->postf[lane]);
+            HK_UNROLL for (int k = 0; k < T::POSTF_LEN / 4; k++) codes[k] = row[k];
             Fq acc = Fq::zero();
-            u32 pos = 0;
-            for (int lev = 0; lev < T::NLEVELS; lev++) {
+            int pos = 0;
+            HK_UNROLL for (int lev = 0; lev < T::NLEVELS; lev++) {
                 if (lev) acc = Fq::dbl(acc);
-                u32 cnt = s[pos++];
-                for (u32 e = 0; e < cnt; e++) {
-                    u32 code = s[pos + e];
-                    Fq v = w->prod[code & 0x7f];
-                    acc = (code & 0x80) ? Fq::sub(acc, v) : Fq::add(acc, v);
-                }
-                pos += cnt;
+                HK_UNROLL for (int e = 0; e < T::n_add(lev); e++, pos++)
+                    acc = Fq::add(acc, w->prod[(codes[pos >> 2] >> (8 * (pos & 3))) & 0xff]);
+                HK_UNROLL for (int e = 0; e < T::n_sub(lev); e++, pos++)
+                    acc = Fq::sub(acc, w->prod[(codes[pos >> 2] >> (8 * (pos & 3))) & 0xff]);
             }
             w->part[lane] = acc;
         }
@@ -326,6 +348,7 @@ k_pair_tree_lines(const Line6<P>* __restrict__ lines, u32 n, u32 c, Fp12<P>* __r
     typedef TowerParams<P> T;
     WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
     Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    WaveF12<P>::init(w);
     Fq *acc = s, *cur = s + WV_SLOT;
     u32 lo = blockIdx.x * c, hi = min(lo + c, n);
     const Line6<P>* src = lines + (size_t)blockIdx.y * n;
@@ -362,6 +385,7 @@ k_pair_horner(const Fp12<P>* __restrict__ L, PairSteps st, Fp12<P>* __restrict__
     typedef Fp<P> Fq;
     WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
     Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    WaveF12<P>::init(w);
     Fq* acc = s;
     Fq* cur = s + 9 * WV_SLOT;
     const Fp12<P>* src = L + (size_t)blockIdx.x * st.n;
@@ -386,6 +410,7 @@ k_pair_finish(const Fp12<P>* __restrict__ in, u32 n, Fp12<P>* __restrict__ out) 
     typedef Fp<P> Fq;
     WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
     Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    WaveF12<P>::init(w);
     const Fp12<P>* src = in + (size_t)blockIdx.x * n;
     Fq* acc = s;
     Fq* cur = s + 9 * WV_SLOT;
@@ -408,6 +433,7 @@ k_pair_tree(const Fp12<P>* __restrict__ in, u32 n, u32 c, Fp12<P>* __restrict__ 
     typedef Fp<P> Fq;
     WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
     Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    WaveF12<P>::init(w);
     Fq *acc = s, *cur = s + WV_SLOT;
     u32 lo = blockIdx.x * c, hi = min(lo + c, n);
     const Fp12<P>* src = in + (size_t)blockIdx.y * n;
@@ -431,6 +457,7 @@ k_gt_pow(const Fp12<P>* __restrict__ in, const Fr* __restrict__ scalars_mont, u3
     __shared__ u32 kbits[Fr::N];
     WaveArea<P>* w = reinterpret_cast<WaveArea<P>*>(pair_lds);
     Fq* s = reinterpret_cast<Fq*>(pair_lds + sizeof(WaveArea<P>));
+    WaveF12<P>::init(w);
     Fq *base = s, *acc = s + WV_SLOT;
     if (blockIdx.x >= n) return;
     if (threadIdx.x == 0) {
