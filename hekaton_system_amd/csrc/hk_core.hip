@@ -283,6 +283,11 @@ hk_status hk_points_lincomb_g2(hk_ctx* ctx, const void* const* vecs, const void*
     if (!ctx || !vecs || !coeffs_mont || (n && !out)) return HK_ERR_ARG;
     return ctx->ops->points_lincomb(ctx, 2, vecs, coeffs_mont, k, n, out);
 }
+hk_status hk_points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4_mont, unsigned neg_mask, size_t n,
+                            void* out) {
+    if (!ctx || !ctx->ops) return HK_ERR_ARG;
+    return ctx->ops->points_fold_g2(ctx, lo, hi, coeffs4_mont, neg_mask, n, out);
+}
 hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2,
                               size_t n_rhs, size_t n, void* gt_out) {
     if (!ctx || !lhs_g1 || !rhs_g2 || !gt_out) return HK_ERR_ARG;

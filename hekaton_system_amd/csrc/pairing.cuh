@@ -93,6 +93,37 @@ HK_HD Affine<Fp2<P>> pair_mul_by_char(const Affine<Fp2<P>>& q) {       // ark bn
     return r;
 }
 
+// psi(Q) = [q mod r] Q on G2 (the untwist-Frobenius-twist endomorphism; eigenvalue 6x^2 on BN254, x on BLS12-381):
+// what lets a scalar multiplication in G2 run over four ~64-bit sub-scalars (hk_points_fold_g2).  (0, 0) -> (0, 0).
+template <class P>
+HK_HD Affine<Fp2<P>> g2_psi(const Affine<Fp2<P>>& q) {
+    typedef TowerParams<P> T;
+    Affine<Fp2<P>> r;
+    r.x = f2m(f2_conj(q.x), fp2_const<P>(T::PSI_X));
+    r.y = f2m(f2_conj(q.y), fp2_const<P>(T::PSI_Y));
+    return r;
+}
+
+#if defined(__HIPCC__)
+// out_j[i] = (neg_mask bit j ? - : +) psi^j(pts[i]),  j = 0..3
+template <class P>
+__global__ void __launch_bounds__(64)
+k_points_psi4(const Affine<Fp2<P>>* __restrict__ pts, u32 n, u32 neg_mask, Affine<Fp2<P>>* __restrict__ o0,
+              Affine<Fp2<P>>* __restrict__ o1, Affine<Fp2<P>>* __restrict__ o2, Affine<Fp2<P>>* __restrict__ o3) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<Fp2<P>> t = ld_vec(&pts[i]);
+    const bool inf = t.is_inf();                                   // psi(O) = O, -O = O: written as (0, 0) explicitly
+    Affine<Fp2<P>>* outs[4] = {o0, o1, o2, o3};
+    HK_NOUNROLL for (int j = 0; j < 4; j++) {
+        if (j && !inf) t = g2_psi(t);
+        Affine<Fp2<P>> w = t;
+        if (!inf && ((neg_mask >> j) & 1)) w.y = Fp2<P>::neg(w.y);
+        st_vec(&outs[j][i], w);
+    }
+}
+#endif
+
 // Miller value of ONE pair (1 when either member is infinity: ark's multi_miller_loop skips such pairs)
 template <class P>
 HK_RARE Fp12<P> pair_miller_one(const Affine<Fp<P>>& p, const Affine<Fp2<P>>& q, const PairLoop& loop) {

@@ -853,6 +853,51 @@ hk_status Ops<C>::points_lincomb(hk_ctx* ctx, int group, const void* const* vecs
     return group == 1 ? run(Fq()) : run(Fq2());
 }
 
+// out[i] = lo[i] + sum_{j<4} (+-) coeffs4[j] * psi^j(hi[i]) in G2: the fold lo + c * hi of a TIPA round with c split into
+// four ~64-bit parts on the host (c = sum +-coeffs4[j] lambda^j mod r, lambda = psi's eigenvalue), so the shared doubling
+// chain of the element-wise combination is ~66 steps instead of 254
+template <class C>
+hk_status Ops<C>::points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4, unsigned neg_mask,
+                                 size_t n, void* out) {
+    typedef typename Fq::Params P;
+    typedef Fq2 F;
+    if (n == 0) return HK_OK;
+    if (!lo || !hi || !coeffs4 || !out || n >= (1u << 28) || neg_mask > 15) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    size_t need = 7 * al256(n * sizeof(Affine<F>)) + al256(5 * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) + al256(n * sizeof(F)) + 8192;
+    HK_TRY(L->reserve(need));
+    const void *lod, *hid;
+    HK_TRY(to_device(L, lo, n * sizeof(Affine<F>), &lod));
+    HK_TRY(to_device(L, hi, n * sizeof(Affine<F>), &hid));
+    Affine<F>* t[4];
+    for (auto& x : t) { x = L->alloc_n<Affine<F>>(n); if (!x) return HK_ERR_NOMEM; }
+    HK_TRY(PairRun<P>::psi4(L->stream, (const Affine<F>*)hid, (u32)n, neg_mask, t));
+    // coefficients: 1 for lo, then the four small magnitudes
+    Fr* cd = L->alloc_n<Fr>(5);
+    if (!cd) return HK_ERR_NOMEM;
+    Fr one = Fr::one();
+    if (is_device_ptr(coeffs4)) {
+        HK_HIP(hipMemcpyAsync(cd + 1, coeffs4, 4 * sizeof(Fr), hipMemcpyDeviceToDevice, L->stream));
+    } else {
+        HK_HIP(hipMemcpyAsync(cd + 1, coeffs4, 4 * sizeof(Fr), hipMemcpyHostToDevice, L->stream));
+        HK_HIP(hipStreamSynchronize(L->stream));          // the caller's buffer is pageable: done with it before returning
+    }
+    HK_HIP(hipMemcpyAsync(cd, &one, sizeof(Fr), hipMemcpyHostToDevice, L->stream));
+    HK_HIP(hipStreamSynchronize(L->stream));              // `one` lives on this stack frame
+    const Affine<F>* dv[LINCOMB_MAX] = {(const Affine<F>*)lod, t[0], t[1], t[2], t[3]};
+    XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
+    F* pref = L->alloc_n<F>(n);
+    bool out_dev = is_device_ptr(out);
+    Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
+    if (!xy || !pref || !od) return HK_ERR_NOMEM;
+    HK_TRY(MsmRun<F>::lincomb(L->stream, dv, cd, 5u, (u32)n, xy, pref, od));
+    if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+    HK_HIP(hipStreamSynchronize(L->stream));
+    return HK_OK;
+}
+
 // z[i] = bits[i] ? 1 : 0 (Montgomery), then z[full_cols[k]] = full_vals[k]
 template <class Fr>
 __global__ void k_expand_bits(const unsigned char* __restrict__ bits, size_t n, Fr* __restrict__ z) {

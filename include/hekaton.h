@@ -188,6 +188,13 @@ hk_status hk_gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, si
  * vecs [h]: k pointers, each [h|d] to n packed affine points; coeffs_mont [h|d]: k Fr; out [h|d]: n packed affine. */
 hk_status hk_points_lincomb_g1(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out);
 hk_status hk_points_lincomb_g2(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out);
+/* out[i] = lo[i] + sum_{j<4} s_j * coeffs4[j] * psi^j(hi[i]) in G2, s_j = -1 where bit j of neg_mask is set: the G2 fold
+ * `lo + c * hi` of a TIPA / GIPA round (ark-ip-proofs `gipa`, called from distributed-prover/src/aggregation.rs:340) with the
+ * challenge split by the caller into four ~64-bit parts along psi, the untwist-Frobenius-twist endomorphism of G2
+ * (psi(Q) = [q mod r] Q: c = sum s_j coeffs4[j] lambda^j mod r with lambda = 6 x^2 on BN254, x on BLS12-381) - the shared
+ * doubling chain is ~66 steps instead of 254.  lo, hi [h|d]: n G2 points; coeffs4_mont [h|d]: 4 Fr; out [h|d]: n G2. */
+hk_status hk_points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4_mont, unsigned neg_mask, size_t n,
+                            void* out);
 
 /* ---- MSM over a RESIDENT base set ----------------------------------------------------------------------
  * Bases that are key material (the KZG / commitment-key powers of the aggregator's SRS, any static query) are

@@ -93,3 +93,30 @@ def test_aggregation_front_half_on_real_proofs(ctx_bn254):
         apk.agg_front(super_com, bad, pub, twist, s, t)
     for _c, _pk, dpk in keys.values():
         dpk.free()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_g2_fold_along_the_endomorphism_equals_the_plain_combination(cname, ctx_bn254, ctx_bls):
+    """hk_points_fold_g2 (the challenge split into four ~64-bit parts along psi) gives, element by element and byte for
+    byte, what hk_points_lincomb_g2 gives for lo + c * hi with the full 254 / 255-bit scalar - including infinity on either
+    side, c = 0, 1, r - 1 and the eigenvalue itself."""
+    from hekaton_system_amd.endo import psi4
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    fc = FrCodec(cname)
+    from hekaton_system_amd.cp_groth16 import CURVE_PARAMS
+    p = CURVE_PARAMS[cname]
+    rnd = random.Random(31)
+    n = 37
+    g2b = ctx.g2_bytes
+    gen2 = fc.g2(p["g2"])
+    lo = ctx.fixed_base(2, gen2, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])).copy()
+    hi = ctx.fixed_base(2, gen2, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])).copy()
+    lo[3 * g2b:4 * g2b] = 0                                   # infinity in lo
+    hi[5 * g2b:6 * g2b] = 0                                   # infinity in hi
+    lo[7 * g2b:8 * g2b] = 0
+    hi[7 * g2b:8 * g2b] = 0                                   # both
+    lam = psi4(cname).lam
+    for c in [0, 1, 2, p["r"] - 1, lam, p["r"] - lam, (1 << 64) + 1] + [rnd.randrange(p["r"]) for _ in range(4)]:
+        want = ctx.points_lincomb(2, [lo, hi], fc.enc([1, c]), n=n)
+        got = ctx.points_fold_g2(lo, hi, c, n=n)
+        assert np.array_equal(got, want), c

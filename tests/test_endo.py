@@ -1,0 +1,61 @@
+"""The G2 endomorphism behind hk_points_fold_g2 (hekaton_system_amd/endo.py, csrc/pairing.cuh g2_psi), checked on the CPU
+against the oracle's curve arithmetic: psi(Q) = (conj(x) * PSI_X, conj(y) * PSI_Y) has the eigenvalue q mod r on G2 (6 x^2
+on BN254, x on BLS12-381) with exactly the constants the generator emits for each twist type, and every scalar splits into
+four parts of at most 65 bits that recombine to it."""
+import random
+import re
+
+import pytest
+
+from hekaton_system_amd.endo import eigenvalue, psi4
+from oracle.pyref import curve
+from oracle.pyref.params import CURVES
+
+
+def _f2m(a, b, q):
+    return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+
+
+def _psi_constants(name):
+    """(PSI_X, PSI_Y) as the product's generated header holds them (Montgomery limbs -> ints)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "hekaton_system_amd", "csrc", "hk_tower_params.h")).read()
+    cp = CURVES[name]
+    pre = "HK_%s_TW" % ("BN254" if name == "bn254" else "BLS12_381")
+    out = []
+    for key in ("PSI_X", "PSI_Y"):
+        m = re.search(r"#define %s_%s \{ \{ ([^}]*) \}, \{ ([^}]*) \} \}" % (pre, key), txt)
+        comps = []
+        for g in m.groups():
+            limbs = [int(x.strip().rstrip("u"), 16) for x in g.split(",")]
+            v = sum(l << (32 * i) for i, l in enumerate(limbs))
+            comps.append(v * pow(1 << (32 * len(limbs)), -1, cp.q) % cp.q)
+        out.append(tuple(comps))
+    return out
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_psi_has_the_eigenvalue_q_mod_r_on_g2(name):
+    cp = CURVES[name]
+    G2 = curve.G2(cp)
+    lam = eigenvalue(name)
+    assert lam == cp.q % cp.r
+    px, py = _psi_constants(name)
+    rnd = random.Random(2)
+    for _ in range(3):
+        Q = G2.mul(cp.g2_gen, rnd.randrange(1, cp.r))
+        conj = lambda a: (a[0], (-a[1]) % cp.q)
+        img = (_f2m(conj(Q[0]), px, cp.q), _f2m(conj(Q[1]), py, cp.q))
+        want = G2.mul(Q, lam)
+        assert img == (want[0], want[1])
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_every_scalar_splits_into_four_short_parts(name):
+    P = psi4(name)
+    rnd = random.Random(5)
+    for c in [0, 1, P.r - 1, P.lam, P.r - P.lam, 1 << 200] + [rnd.randrange(P.r) for _ in range(500)]:
+        k = P.decompose(c)
+        assert sum(kj * pow(P.lam, j, P.r) for j, kj in enumerate(k)) % P.r == c % P.r
+        assert max(abs(x) for x in k).bit_length() <= 65

@@ -9,7 +9,7 @@ VGPRs / AGPRs, scratch bytes per lane (.private_segment_fixed_size), dynamic-sta
   1. no device FUNCTION (non-kernel symbol) may be larger than the reach of `s_cbranch` (+-32767 dwords = 131 068 B):
      above it hipcc's branch relaxation emits long jumps through `s_getpc_b64 s[30:31]` / `s_setpc_b64 s[30:31]` in
      leaf functions, i.e. through the function's own return address, which a leaf never saves;
-  2. no `s_getpc_b64 s[30:31]` anywhere (the direct signature of that miscompile);
+  2. no `s_getpc_b64 s[30:31]` ... `s_setpc_b64 s[30:31]` sequence anywhere (the direct signature of that miscompile);
   3. no kernel may use a dynamic stack or need more private memory per lane than SCRATCH_LIMIT_BYTES.
 """
 import os
@@ -48,10 +48,19 @@ def function_sizes(co):
 
 
 def retaddr_long_branches(co):
-    """Number of `s_getpc_b64 s[30:31]` in the code object's disassembly."""
+    """Number of long-branch expansions through the return-address pair: `s_getpc_b64 s[30:31]` whose value reaches an
+    `s_setpc_b64 s[30:31]` within the next few instructions (getpc / add / addc / setpc).  A lone `s_getpc_b64 s[30:31]`
+    is ordinary pc-relative addressing (a kernel loading a constant table, a call sequence ending in s_swappc) and a lone
+    `s_setpc_b64 s[30:31]` is an ordinary return."""
     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True,
                          capture_output=True, check=True).stdout
-    return dis.count("s_getpc_b64 s[30:31]")
+    lines = [l.strip() for l in dis.splitlines() if l.startswith("\t") or l.startswith(" ")]
+    n = 0
+    for i, l in enumerate(lines):
+        if l.startswith("s_getpc_b64 s[30:31]"):
+            if any(x.startswith("s_setpc_b64 s[30:31]") for x in lines[i + 1:i + 5]):
+                n += 1
+    return n
 
 
 def code_objects(path):
