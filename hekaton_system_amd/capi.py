@@ -62,7 +62,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow"]
 
 _lib = None
 
@@ -111,6 +111,8 @@ def load():
             f.argtypes = [vp, C.POINTER(vp), vp, sz, sz, vp]
     if hasattr(lib, "hk_points_fold_g2"):
         lib.hk_points_fold_g2.argtypes = [vp, vp, vp, vp, C.c_uint, sz, vp]
+    if hasattr(lib, "hk_points_fold_g1"):
+        lib.hk_points_fold_g1.argtypes = [vp, vp, vp, vp, C.c_uint, sz, vp]
     if hasattr(lib, "hk_assignment_from_bits"):
         lib.hk_assignment_from_bits.argtypes = [vp, vp, sz, vp, vp, sz, vp]
         lib.hk_wprog_upload.argtypes = [vp, vp, sz, vp, sz, vp, sz, sz, sz, C.POINTER(vp)]
@@ -317,6 +319,22 @@ class Context:
         out = np.zeros(n * self.g2_bytes, dtype=np.uint8)
         check(self.lib.hk_points_fold_g2(self.handle, ptr(lo_), ptr(hi_), coeffs.ctypes.data, neg, n, out.ctypes.data),
               "hk_points_fold_g2")
+        return out
+
+    def points_fold_g1(self, lo, hi, c, n=None):
+        """out[i] = lo[i] + c * hi[i] in G1 through hk_points_fold_g1: c split along the GLV endomorphism into two ~128-bit
+        parts (endo.Phi2)."""
+        from .cp_groth16 import FrCodec
+        from .endo import phi2
+        n = n if n is not None else len(hi) // self.g1_bytes
+        k = phi2(self.curve).decompose(c)
+        neg = sum(1 << j for j, v in enumerate(k) if v < 0)
+        coeffs = np.ascontiguousarray(FrCodec(self.curve).enc([abs(v) for v in k]), dtype=np.uint8)
+        lo_, hi_ = (x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8) for x in (lo, hi))
+        ptr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data
+        out = np.zeros(n * self.g1_bytes, dtype=np.uint8)
+        check(self.lib.hk_points_fold_g1(self.handle, ptr(lo_), ptr(hi_), coeffs.ctypes.data, neg, n, out.ctypes.data),
+              "hk_points_fold_g1")
         return out
 
     def assignment_from_bits(self, bits, full_cols, full_vals, out=None):

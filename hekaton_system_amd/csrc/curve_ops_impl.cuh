@@ -113,6 +113,7 @@ struct Ops {
     static hk_status pairing_products(hk_ctx*, const void* const*, size_t, const void* const*, size_t, size_t, void*);
     static hk_status points_lincomb(hk_ctx*, int, const void* const*, const void*, size_t, size_t, void*);
     static hk_status points_fold_g2(hk_ctx*, const void*, const void*, const void*, unsigned, size_t, void*);
+    static hk_status points_fold_g1(hk_ctx*, const void*, const void*, const void*, unsigned, size_t, void*);
     static hk_status assignment_from_bits(hk_ctx*, const void*, size_t, const uint32_t*, const void*, size_t, void*);
     static hk_status wprog_upload(hk_ctx*, const uint32_t*, size_t, const uint32_t*, size_t, const uint32_t*, size_t, size_t,
                                   size_t, hk_wprog**);
@@ -125,7 +126,7 @@ struct Ops {
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
-                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb, &points_fold_g2, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow};
+                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb, &points_fold_g2, &points_fold_g1, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow};
         return &t;
     }
 };

@@ -283,6 +283,11 @@ hk_status hk_points_lincomb_g2(hk_ctx* ctx, const void* const* vecs, const void*
     if (!ctx || !vecs || !coeffs_mont || (n && !out)) return HK_ERR_ARG;
     return ctx->ops->points_lincomb(ctx, 2, vecs, coeffs_mont, k, n, out);
 }
+hk_status hk_points_fold_g1(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs2_mont, unsigned neg_mask, size_t n,
+                            void* out) {
+    if (!ctx || !ctx->ops) return HK_ERR_ARG;
+    return ctx->ops->points_fold_g1(ctx, lo, hi, coeffs2_mont, neg_mask, n, out);
+}
 hk_status hk_points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4_mont, unsigned neg_mask, size_t n,
                             void* out) {
     if (!ctx || !ctx->ops) return HK_ERR_ARG;

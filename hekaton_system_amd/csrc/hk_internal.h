@@ -116,6 +116,8 @@ struct CurveOps {
                                 void* out);
     hk_status (*points_fold_g2)(hk_ctx*, const void* lo, const void* hi, const void* coeffs4, unsigned neg_mask, size_t n,
                                 void* out);
+    hk_status (*points_fold_g1)(hk_ctx*, const void* lo, const void* hi, const void* coeffs2, unsigned neg_mask, size_t n,
+                                void* out);
     hk_status (*assignment_from_bits)(hk_ctx*, const void* bits, size_t n_v, const uint32_t* full_cols,
                                       const void* full_vals, size_t n_full, void* z_out);
     hk_status (*wprog_upload)(hk_ctx*, const uint32_t* ops, size_t n_ops, const uint32_t* refs, size_t n_refs,

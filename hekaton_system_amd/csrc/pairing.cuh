@@ -122,6 +122,27 @@ k_points_psi4(const Affine<Fp2<P>>* __restrict__ pts, u32 n, u32 neg_mask, Affin
         st_vec(&outs[j][i], w);
     }
 }
+// out_j[i] = (neg_mask bit j ? - : +) phi^j(pts[i]), j = 0, 1, phi(x, y) = (BETA x, y): the GLV endomorphism of G1
+template <class P>
+__global__ void __launch_bounds__(64)
+k_points_phi2(const Affine<Fp<P>>* __restrict__ pts, u32 n, u32 neg_mask, Affine<Fp<P>>* __restrict__ o0,
+              Affine<Fp<P>>* __restrict__ o1) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef Fp<P> Fq;
+    Affine<Fq> t = ld_vec(&pts[i]);
+    const bool inf = t.is_inf();
+    Affine<Fq> a = t, b = t;
+    if (!inf) {
+        Fq beta;
+        for (int k = 0; k < P::N; k++) beta.v[k] = TowerParams<P>::BETA[k];
+        b.x = Fq::mul(t.x, beta);
+        if (neg_mask & 1) a.y = Fq::neg(a.y);
+        if (neg_mask & 2) b.y = Fq::neg(b.y);
+    }
+    st_vec(&o0[i], a);
+    st_vec(&o1[i], b);
+}
 #endif
 
 // Miller value of ONE pair (1 when either member is infinity: ark's multi_miller_loop skips such pairs)

@@ -898,6 +898,44 @@ hk_status Ops<C>::points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, co
     return HK_OK;
 }
 
+// out[i] = lo[i] + (+-) coeffs2[0] * hi[i] + (+-) coeffs2[1] * phi(hi[i]) in G1: the G1 fold lo + c * hi with c split along the
+// GLV endomorphism phi(x, y) = (BETA x, y) into two ~128-bit parts on the host (128 doubling steps instead of 254)
+template <class C>
+hk_status Ops<C>::points_fold_g1(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs2, unsigned neg_mask,
+                                 size_t n, void* out) {
+    typedef typename Fq::Params P;
+    typedef Fq F;
+    if (n == 0) return HK_OK;
+    if (!lo || !hi || !coeffs2 || !out || n >= (1u << 28) || neg_mask > 3) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    size_t need = 5 * al256(n * sizeof(Affine<F>)) + al256(3 * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) + al256(n * sizeof(F)) + 8192;
+    HK_TRY(L->reserve(need));
+    const void *lod, *hid;
+    HK_TRY(to_device(L, lo, n * sizeof(Affine<F>), &lod));
+    HK_TRY(to_device(L, hi, n * sizeof(Affine<F>), &hid));
+    Affine<F>* t[2];
+    for (auto& x : t) { x = L->alloc_n<Affine<F>>(n); if (!x) return HK_ERR_NOMEM; }
+    HK_TRY(PairRun<P>::phi2(L->stream, (const Affine<F>*)hid, (u32)n, neg_mask, t));
+    Fr* cd = L->alloc_n<Fr>(3);
+    if (!cd) return HK_ERR_NOMEM;
+    Fr one = Fr::one();
+    HK_HIP(hipMemcpyAsync(cd + 1, coeffs2, 2 * sizeof(Fr), is_device_ptr(coeffs2) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, L->stream));
+    HK_HIP(hipMemcpyAsync(cd, &one, sizeof(Fr), hipMemcpyHostToDevice, L->stream));
+    HK_HIP(hipStreamSynchronize(L->stream));              // `one` and a pageable coeffs2 are done with before returning
+    const Affine<F>* dv[LINCOMB_MAX] = {(const Affine<F>*)lod, t[0], t[1]};
+    XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
+    F* pref = L->alloc_n<F>(n);
+    bool out_dev = is_device_ptr(out);
+    Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
+    if (!xy || !pref || !od) return HK_ERR_NOMEM;
+    HK_TRY(MsmRun<F>::lincomb(L->stream, dv, cd, 3u, (u32)n, xy, pref, od));
+    if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+    HK_HIP(hipStreamSynchronize(L->stream));
+    return HK_OK;
+}
+
 // z[i] = bits[i] ? 1 : 0 (Montgomery), then z[full_cols[k]] = full_vals[k]
 template <class Fr>
 __global__ void k_expand_bits(const unsigned char* __restrict__ bits, size_t n, Fr* __restrict__ z) {

@@ -28,6 +28,7 @@ template <class P> struct TowerParams;
         static constexpr u32 FROB12_C1[3][2][FQP::N] = {PRE##_FROB12_C1_1, PRE##_FROB12_C1_2, PRE##_FROB12_C1_3}; \
         static constexpr u32 MUL_BY_Q_X[2][FQP::N] = PRE##_MUL_BY_Q_X;                                  \
         static constexpr u32 MUL_BY_Q_Y[2][FQP::N] = PRE##_MUL_BY_Q_Y;                                  \
+        static constexpr u32 BETA[FQP::N] = PRE##_BETA;                                                 \
         static constexpr u32 PSI_X[2][FQP::N] = PRE##_PSI_X;                                            \
         static constexpr u32 PSI_Y[2][FQP::N] = PRE##_PSI_Y;                                            \
     };

@@ -98,7 +98,67 @@ class Psi4:
         return k
 
 
+def _g1_mul(P, k, q):
+    """k * P on y^2 = x^3 + b over Fq (affine, plain double-and-add; used once per curve to pick phi's eigenvalue)."""
+    def add(A, B):
+        if A is None:
+            return B
+        if B is None:
+            return A
+        if A[0] == B[0]:
+            if (A[1] + B[1]) % q == 0:
+                return None
+            lam = 3 * A[0] * A[0] * pow(2 * A[1], -1, q) % q
+        else:
+            lam = (B[1] - A[1]) * pow(B[0] - A[0], -1, q) % q
+        x = (lam * lam - A[0] - B[0]) % q
+        return (x, (lam * (A[0] - x) - A[1]) % q)
+    R, Q = None, P
+    while k:
+        if k & 1:
+            R = add(R, Q)
+        Q = add(Q, Q)
+        k >>= 1
+    return R
+
+
+class Phi2:
+    """The GLV endomorphism of G1, phi(x, y) = (beta x, y) with beta the first g^((q-1)/3) != 1 (g = 2, 3, ...: the constant
+    csrc/gen_tower_params.py emits as BETA), and its eigenvalue lambda (the root of X^2 + X + 1 mod r with
+    phi(G) = [lambda] G, found by trying both).  decompose(c) -> [k0, k1] with k0 + k1 lambda = c mod r, |kj| ~ 2^127."""
+
+    def __init__(self, curve):
+        p = CURVE_PARAMS[curve]
+        q, r = p["q"], p["r"]
+        self.r = r
+        self.beta = next(b for b in (pow(g, (q - 1) // 3, q) for g in range(2, 50)) if b != 1)
+        G = tuple(p["g1"])
+        image = (self.beta * G[0] % q, G[1])
+        w = next(x for x in (pow(g, (r - 1) // 3, r) for g in range(2, 50)) if x != 1)
+        self.lam = next(l for l in (w, w * w % r) if _g1_mul(G, l, q) == image)
+        self.basis = _lll([[r, 0], [-self.lam, 1]])
+        for v in self.basis:
+            assert (v[0] + v[1] * self.lam) % r == 0
+        self.inv = _inverse(self.basis)
+
+    def decompose(self, c):
+        c %= self.r
+        t = [round(c * self.inv[0][j]) for j in range(2)]
+        k = [c, 0]
+        for j in range(2):
+            for i in range(2):
+                k[i] -= t[j] * self.basis[j][i]
+        return k
+
+
 _CACHE = {}
+
+
+def phi2(curve):
+    key = ("phi", curve)
+    if key not in _CACHE:
+        _CACHE[key] = Phi2(curve)
+    return _CACHE[key]
 
 
 def psi4(curve):

@@ -138,9 +138,10 @@ class Tipp:
         return buf[:h], buf[h:]
 
     def _fold(self, group, lo, hi, coeff, n):
-        if group == 2:           # G2: the challenge split along the endomorphism psi (66 doubling steps instead of 254)
+        # the challenge split along an endomorphism: psi on G2 (66 doubling steps instead of 254), GLV's phi on G1 (128)
+        if group == 2:
             return self.ctx.points_fold_g2(lo, hi, coeff, n=n)
-        return self.ctx.points_lincomb(group, [lo, hi], self.fc.enc([1, coeff]), n=n)
+        return self.ctx.points_fold_g1(lo, hi, coeff, n=n)
 
     def _powers(self, x, n):
         out = [1] * n

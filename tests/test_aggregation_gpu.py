@@ -120,3 +120,28 @@ def test_g2_fold_along_the_endomorphism_equals_the_plain_combination(cname, ctx_
         want = ctx.points_lincomb(2, [lo, hi], fc.enc([1, c]), n=n)
         got = ctx.points_fold_g2(lo, hi, c, n=n)
         assert np.array_equal(got, want), c
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_g1_fold_along_the_glv_endomorphism_equals_the_plain_combination(cname, ctx_bn254, ctx_bls):
+    """hk_points_fold_g1 against hk_points_lincomb_g1 for lo + c * hi, byte for byte, infinity included."""
+    from hekaton_system_amd.cp_groth16 import CURVE_PARAMS
+    from hekaton_system_amd.endo import phi2
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    fc = FrCodec(cname)
+    p = CURVE_PARAMS[cname]
+    rnd = random.Random(32)
+    n = 41
+    g1b = ctx.g1_bytes
+    gen1 = fc.g1(p["g1"])
+    lo = ctx.fixed_base(1, gen1, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])).copy()
+    hi = ctx.fixed_base(1, gen1, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])).copy()
+    lo[2 * g1b:3 * g1b] = 0
+    hi[4 * g1b:5 * g1b] = 0
+    lo[6 * g1b:7 * g1b] = 0
+    hi[6 * g1b:7 * g1b] = 0
+    lam = phi2(cname).lam
+    for c in [0, 1, 2, p["r"] - 1, lam, p["r"] - lam, (1 << 127) + 5] + [rnd.randrange(p["r"]) for _ in range(4)]:
+        want = ctx.points_lincomb(1, [lo, hi], fc.enc([1, c]), n=n)
+        got = ctx.points_fold_g1(lo, hi, c, n=n)
+        assert np.array_equal(got, want), c

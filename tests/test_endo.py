@@ -59,3 +59,30 @@ def test_every_scalar_splits_into_four_short_parts(name):
         k = P.decompose(c)
         assert sum(kj * pow(P.lam, j, P.r) for j, kj in enumerate(k)) % P.r == c % P.r
         assert max(abs(x) for x in k).bit_length() <= 65
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_g1_endomorphism_eigenvalue_and_two_part_split(name):
+    """phi(x, y) = (beta x, y) with the generator's BETA acts on G1 as multiplication by endo.Phi2.lam (oracle curve
+    arithmetic), lam^2 + lam + 1 = 0 mod r, and every scalar splits into two parts of at most 129 bits."""
+    import os
+    from hekaton_system_amd.endo import phi2
+    cp = CURVES[name]
+    P = phi2(name)
+    assert (P.lam * P.lam + P.lam + 1) % cp.r == 0 and pow(P.beta, 3, cp.q) == 1 and P.beta != 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "hekaton_system_amd", "csrc", "hk_tower_params.h")).read()
+    pre = "HK_%s_TW" % ("BN254" if name == "bn254" else "BLS12_381")
+    m = re.search(r"#define %s_BETA \{ ([^}]*) \}" % pre, txt)
+    limbs = [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+    beta_hdr = sum(l << (32 * i) for i, l in enumerate(limbs)) * pow(1 << (32 * len(limbs)), -1, cp.q) % cp.q
+    assert beta_hdr == P.beta
+    G1 = curve.G1(cp)
+    rnd = random.Random(9)
+    for _ in range(3):
+        Q = G1.mul(cp.g1_gen, rnd.randrange(1, cp.r))
+        want = G1.mul(Q, P.lam)
+        assert (P.beta * Q[0] % cp.q, Q[1]) == (want[0], want[1])
+    for c in [0, 1, cp.r - 1, P.lam, cp.r - P.lam] + [rnd.randrange(cp.r) for _ in range(500)]:
+        k = P.decompose(c)
+        assert (k[0] + k[1] * P.lam) % cp.r == c % cp.r and max(abs(x) for x in k).bit_length() <= 129
