@@ -62,7 +62,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow"]
 
 _lib = None
 

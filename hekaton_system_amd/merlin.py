@@ -35,8 +35,38 @@ def _rol(x, n):
     return ((x << n) | (x >> (64 - n))) & _MASK if n else x
 
 
+_NATIVE = None
+
+
+def _native():
+    """libhekaton's host-side hk_keccak_f1600 (plain C; 100 x the speed of the Python permutation below), or False."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            import ctypes
+            from . import capi
+            fn = capi.load().hk_keccak_f1600
+            fn.argtypes = [ctypes.c_void_p]
+            fn.restype = None
+            _NATIVE = (fn, ctypes)
+        except Exception:       # noqa: BLE001  (library not built: the Python permutation is the same function)
+            _NATIVE = False
+    return _NATIVE
+
+
 def keccak_f1600(state):
     """In-place Keccak-f[1600] on a 200-byte bytearray (lanes little-endian, lane (x, y) at 8 * (x + 5 y))."""
+    nat = _native()
+    if nat:
+        fn, ctypes = nat
+        buf = (ctypes.c_ubyte * 200).from_buffer(state)
+        fn(ctypes.addressof(buf))
+        return
+    keccak_f1600_py(state)
+
+
+def keccak_f1600_py(state):
+    """The permutation in plain Python (reference form of the above; used when the library is not built)."""
     a = list(struct.unpack("<25Q", state))
     for rnd in range(24):
         c = [a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20] for x in range(5)]
@@ -72,9 +102,14 @@ class Strobe128:
         self.pos = self.pos_begin = 0
 
     def _absorb(self, data):
-        for byte in data:
-            self.state[self.pos] ^= byte
-            self.pos += 1
+        data = bytes(data)
+        off = 0
+        while off < len(data):
+            k = min(STROBE_R - self.pos, len(data) - off)
+            chunk = int.from_bytes(data[off:off + k], "little") ^ int.from_bytes(self.state[self.pos:self.pos + k], "little")
+            self.state[self.pos:self.pos + k] = chunk.to_bytes(k, "little")
+            self.pos += k
+            off += k
             if self.pos == STROBE_R:
                 self._run_f()
 

@@ -195,6 +195,10 @@ hk_status hk_points_lincomb_g2(hk_ctx* ctx, const void* const* vecs, const void*
  * doubling chain is ~66 steps instead of 254.  lo, hi [h|d]: n G2 points; coeffs4_mont [h|d]: 4 Fr; out [h|d]: n G2. */
 hk_status hk_points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4_mont, unsigned neg_mask, size_t n,
                             void* out);
+/* Host utility (no device work): Keccak-f[1600] on 25 little-endian 64-bit lanes - the permutation under the merlin
+ * transcripts (STROBE-128) the aggregator draws its challenges from (distributed-prover/src/util.rs:22,41-75). */
+void hk_keccak_f1600(uint64_t* state25);
+
 /* The same for G1 along the GLV endomorphism phi(x, y) = (beta x, y) (phi(P) = [lambda] P, lambda^2 + lambda + 1 = 0 mod r):
  * out[i] = lo[i] + s_0 coeffs2[0] hi[i] + s_1 coeffs2[1] phi(hi[i]), c = s_0 coeffs2[0] + s_1 coeffs2[1] lambda mod r with two
  * ~128-bit parts - the folds `A' = A_L + c A_R`, `w' = w_L + c w_R` of a round.  128 doubling steps instead of 254. */

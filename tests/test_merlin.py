@@ -68,3 +68,20 @@ def test_challenge_scalar_is_a_reduced_field_element():
         x = t.challenge_scalar(b"r-random-fiatshamir", r)
         y = t.challenge_scalar(b"s-random-fiatshamir", r)
         assert 0 <= x < r and 0 <= y < r and x != y
+
+
+def test_native_permutation_equals_the_python_one():
+    """libhekaton's host-side hk_keccak_f1600 (what merlin.py uses when the library is built) and the plain-Python
+    permutation are the same function; the transcript KAT above runs on whichever is active."""
+    import random
+    from hekaton_system_amd import merlin
+    if not merlin._native():
+        import pytest
+        pytest.skip("libhekaton.so not built")
+    rnd = random.Random(1)
+    for _ in range(20):
+        st = bytearray(rnd.getrandbits(8) for _ in range(200))
+        a, b = bytearray(st), bytearray(st)
+        merlin.keccak_f1600(a)
+        merlin.keccak_f1600_py(b)
+        assert a == b
