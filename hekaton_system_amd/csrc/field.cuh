@@ -189,14 +189,16 @@ struct Fp {
         return t;
     }
     HK_HD static Fp neg(const Fp& a) {
+        // branch-free: (2)p - a, masked to 0 when a is 0 (-0 = 0 keeps the result below the bound).  No early return: a
+        // data-dependent exit here diverges inside every loop that negates per lane.
         u32 any = 0;
         HK_UNROLL for (int i = 0; i < N; i++) any |= a.v[i];
-        if (any == 0) return a;                       // -0 = 0 (keeps the result below the bound)
+        const u32 mask = any ? 0xffffffffu : 0u;
         Fp t;
         u64 borrow = 0;
         HK_UNROLL for (int i = 0; i < N; i++) {
             u64 d = (u64)(P::LAZY ? P::MOD2[i] : P::MOD[i]) - a.v[i] - borrow;
-            t.v[i] = (u32)d;
+            t.v[i] = (u32)d & mask;
             borrow = (d >> 32) & 1;
         }
         return t;
