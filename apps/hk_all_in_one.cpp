@@ -13,10 +13,11 @@
 //
 // Host code above the C ABI is the C++ mirror of the cp-groth16 surface (hekaton_system_amd/csrc/host/*.hpp); all
 // arithmetic is in libhekaton (HIP).  Assignments are uploaded once and stay resident (the metric's definition, §④);
-// `--host-inputs` sends them over PCIe per proof instead.  BN254 (what the reference instantiates).
+// `--host-inputs` sends them over PCIe per proof instead.  BN254 (what the reference instantiates) by default,
+// `--curve bls12_381` for the other build of the library (zcash point format on the wire).
 //
 // build:  make -C apps      (g++ -O2 -std=c++17 -pthread ... -lhekaton, rpath = hekaton_system_amd/lib)
-// usage:  hk_all_in_one <job_dir> <out_dir> [--threads T] [--steps K] [--warmup W] [--device D] [--host-inputs]
+// usage:  hk_all_in_one <job_dir> <out_dir> [--threads T] [--steps K] [--warmup W] [--device D] [--host-inputs] [--curve C]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -89,13 +90,14 @@ template <class F> static void parallel_for(size_t n, unsigned threads, F f) {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s <job_dir> <out_dir> [--threads T] [--steps K] [--warmup W] [--device D] [--host-inputs]\n", argv[0]);
+        fprintf(stderr, "usage: %s <job_dir> <out_dir> [--threads T] [--steps K] [--warmup W] [--device D] [--host-inputs] [--curve bn254|bls12_381]\n", argv[0]);
         return 2;
     }
     std::string job = argv[1], out = argv[2];
     unsigned threads = 8, steps = 1, warmup = 0;
     int device = 0;
     bool host_inputs = false;
+    bool bls = false;
     for (int i = 3; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--threads" && i + 1 < argc) threads = (unsigned)atoi(argv[++i]);
@@ -103,12 +105,17 @@ int main(int argc, char** argv) {
         else if (a == "--warmup" && i + 1 < argc) warmup = (unsigned)atoi(argv[++i]);
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--host-inputs") host_inputs = true;
+        else if (a == "--curve" && i + 1 < argc) { std::string c = argv[++i]; bls = c == "bls12_381"; if (!bls && c != "bn254") { fprintf(stderr, "unknown curve %s\n", c.c_str()); return 2; } }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     try {
-        Context ctx(HK_BN254, device);
+        Context ctx(bls ? HK_BLS12_381 : HK_BN254, device);
         const Sizes sz = ctx.sizes();
-        ArkCodecBn254 codec(ctx);
+        std::unique_ptr<ArkCodecBn254> codec_bn(bls ? nullptr : new ArkCodecBn254(ctx));
+        std::unique_ptr<ArkCodecBls381> codec_bls(bls ? new ArkCodecBls381(ctx) : nullptr);
+        auto kappa_of = [&](const std::array<uint8_t, 32>& seed) {
+            return bls ? commitment_randomness_bls12_381(seed) : commitment_randomness_bn254(seed);
+        };
         auto dims = rdv<uint64_t>(job + "/job");                  // n_subcircuits, n_classes
         size_t n_sub = dims.at(0), n_cls = dims.at(1);
         auto t_load = std::chrono::steady_clock::now();
@@ -166,7 +173,7 @@ int main(int argc, char** argv) {
                 const Subcircuit& sc = subs[i];
                 KeyClass& kc = *classes[sc.cls];
                 const Assignment& as = kc.assigns[sc.assign];
-                Bytes kappa = commitment_randomness_bn254(sc.com_seed);                  // committer.rs:85
+                Bytes kappa = kappa_of(sc.com_seed);                                     // committer.rs:85
                 Bytes com(sz.g1);
                 const uint8_t* w0 = host_inputs ? as.host.data() + kc.pk.n_inst * sz.fr
                                                 : (const uint8_t*)as.dev + kc.pk.n_inst * sz.fr;
@@ -178,7 +185,7 @@ int main(int argc, char** argv) {
                 const Subcircuit& sc = subs[i];
                 KeyClass& kc = *classes[sc.cls];
                 const Assignment& as = kc.assigns[sc.assign];
-                Bytes kappa = commitment_randomness_bn254(sc.com_seed);
+                Bytes kappa = kappa_of(sc.com_seed);
                 Proof p;
                 p.a.resize(sz.g1); p.b.resize(sz.g2); p.c.resize(sz.g1);
                 const void* z = host_inputs ? (const void*)as.host.data() : as.dev;
@@ -195,16 +202,18 @@ int main(int argc, char** argv) {
         check(hk_ctx_sync(ctx.raw()), "hk_ctx_sync");
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (size_t i = 0; i < n_sub; i++) {
-            wr(out + "/stage0_resp_" + std::to_string(i) + ".bin", codec.stage0_response_to_wire(resp0[i]));
-            wr(out + "/stage1_resp_" + std::to_string(i) + ".bin", codec.stage1_response_to_wire(resp1[i]));
+            wr(out + "/stage0_resp_" + std::to_string(i) + ".bin",
+               bls ? codec_bls->stage0_response_to_wire(resp0[i]) : codec_bn->stage0_response_to_wire(resp0[i]));
+            wr(out + "/stage1_resp_" + std::to_string(i) + ".bin",
+               bls ? codec_bls->stage1_response_to_wire(resp1[i]) : codec_bn->stage1_response_to_wire(resp1[i]));
         }
         for (auto& kc : classes)
             for (auto& as : kc->assigns)
                 if (as.dev) hk_dev_free(ctx.raw(), as.dev);
-        printf("{\"driver\": \"hk_all_in_one (C++ over the C ABI)\", \"subcircuits\": %zu, \"classes\": %zu, \"threads\": %u, "
+        printf("{\"driver\": \"hk_all_in_one (C++ over the C ABI)\", \"curve\": \"%s\", \"subcircuits\": %zu, \"classes\": %zu, \"threads\": %u, "
                "\"steps\": %u, \"warmup\": %u, \"ms_per_step\": %.3f, \"proofs_per_s\": %.3f, \"inputs\": \"%s\", "
                "\"key_load_s\": %.2f}\n",
-               n_sub, n_cls, threads, steps, warmup, dt / steps * 1e3, n_sub * steps / dt,
+               bls ? "bls12_381" : "bn254", n_sub, n_cls, threads, steps, warmup, dt / steps * 1e3, n_sub * steps / dt,
                host_inputs ? "host (PCIe per proof)" : "resident", load_s);
         return 0;
     } catch (const Error& e) {

@@ -7,8 +7,9 @@
 // Same restatement as hekaton_system_amd/ark_serialize.py / chacha.py (the crates are third-party and absent from
 // the reference tree; PARITY UNPINNED by reference bytes — the two mirrors are checked against each other and against
 // the published ChaCha keystream and generator encodings).  Points cross as the ABI's packed-affine Montgomery bytes;
-// the Montgomery <-> canonical conversion is hk_field_convert (device).  BN254 only: ark-bls12-381 overrides point
-// encoding with the zcash format, which the Python mirror implements.
+// the Montgomery <-> canonical conversion is hk_field_convert (device).  ArkCodecBn254 is ark's default short-Weierstrass
+// encoding; ArkCodecBls381 the zcash format ark-bls12-381 overrides it with (big-endian, Fp2 = c1 || c0, flags in the
+// three top bits of the FIRST byte; uncompressed records only - what the worker protocol carries).
 #pragma once
 #include <algorithm>
 #include <array>
@@ -207,6 +208,124 @@ inline Bytes fr_rand_mont_bn254(ChaCha12Rng& rng) {
 inline Bytes commitment_randomness_bn254(const std::array<uint8_t, 32>& com_seed) {
     ChaCha12Rng rng(com_seed);
     return fr_rand_mont_bn254(rng);
+}
+
+// ---- BLS12-381: the zcash point format (ark-bls12-381 `curves/g1.rs`, `g2.rs` serialization overrides) ------------------
+class ArkCodecBls381 {
+public:
+    static constexpr size_t FQ = 48;
+    explicit ArkCodecBls381(const Context& ctx) : ctx_(ctx) {
+        if (ctx.sizes().fq != FQ) throw SerializationError("ArkCodecBls381 needs a BLS12-381 context");
+    }
+    // group: 1 = G1 (x, y), 2 = G2 (x.c0, x.c1, y.c0, y.c1 in the ABI; c1 || c0 on the wire); uncompressed
+    Bytes points_to_wire(int group, const Bytes& abi) const {
+        const size_t coords = group == 1 ? 2 : 4, pb = coords * FQ, n = abi.size() / pb;
+        Bytes canon(abi.size());
+        if (n) check(hk_field_convert(ctx_.raw(), 1, abi.data(), canon.data(), n * coords, 0), "hk_field_convert");
+        Bytes out(n * pb);
+        for (size_t i = 0; i < n; i++) {
+            const uint8_t* src = &abi[i * pb];
+            bool inf = std::all_of(src, src + pb, [](uint8_t b) { return b == 0; });
+            uint8_t* o = &out[i * pb];
+            for (size_t c = 0; c < coords; c++) {
+                size_t from = group == 1 ? c : (c ^ 1);                         // Fp2: c1 first
+                const uint8_t* le = &canon[i * pb + from * FQ];
+                for (size_t b = 0; b < FQ; b++) o[c * FQ + b] = le[FQ - 1 - b]; // big-endian
+            }
+            if (inf) o[0] |= 0x40;
+        }
+        return out;
+    }
+    Bytes points_from_wire(int group, const uint8_t* buf, size_t n) const {
+        const size_t coords = group == 1 ? 2 : 4, pb = coords * FQ;
+        Bytes canon(n * pb);
+        std::vector<bool> inf(n);
+        for (size_t i = 0; i < n; i++) {
+            Bytes be(buf + i * pb, buf + (i + 1) * pb);
+            uint8_t fl = be[0] & 0xE0;
+            if (fl & 0x80) throw SerializationError("UnexpectedFlags: compression bit");
+            if (fl & 0x20) throw SerializationError("UnexpectedFlags: sort bit on an uncompressed point");
+            be[0] &= 0x1F;
+            inf[i] = (fl & 0x40) != 0;
+            if (inf[i] && !std::all_of(be.begin(), be.end(), [](uint8_t b) { return b == 0; }))
+                throw SerializationError("InvalidData: infinity with non-zero coordinates");
+            for (size_t c = 0; c < coords; c++) {
+                size_t to = group == 1 ? c : (c ^ 1);
+                for (size_t b = 0; b < FQ; b++) canon[i * pb + to * FQ + b] = be[c * FQ + FQ - 1 - b];
+            }
+        }
+        Bytes abi(n * pb);
+        if (n) check(hk_field_convert(ctx_.raw(), 1, canon.data(), abi.data(), n * coords, 1), "hk_field_convert");
+        for (size_t i = 0; i < n; i++) if (inf[i]) memset(&abi[i * pb], 0, pb);
+        return abi;
+    }
+    static void put_u64(Bytes& w, uint64_t v) { for (int i = 0; i < 8; i++) w.push_back((uint8_t)(v >> (8 * i))); }
+    static uint64_t get_u64(const uint8_t* p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
+    void put(Bytes& w, const Bytes& b) const { w.insert(w.end(), b.begin(), b.end()); }
+    Bytes proof_to_wire(const Proof& p) const {
+        Bytes w;
+        put(w, points_to_wire(1, p.a)); put(w, points_to_wire(2, p.b)); put(w, points_to_wire(1, p.c));
+        put_u64(w, p.ds.size());
+        for (auto& d : p.ds) put(w, points_to_wire(1, d));
+        return w;
+    }
+    Bytes stage0_response_to_wire(const Stage0Response& r) const {              // 8 + 96 + 32 = 136 bytes
+        Bytes w;
+        put_u64(w, r.subcircuit_idx);
+        put(w, points_to_wire(1, r.com));
+        w.insert(w.end(), r.com_seed.begin(), r.com_seed.end());
+        return w;
+    }
+    Bytes stage1_response_to_wire(const Stage1Response& r) const {              // 8 + 96 + 192 + 96 + 8 + 96 = 496 bytes
+        Bytes w;
+        put_u64(w, r.subcircuit_idx);
+        put(w, proof_to_wire(r.proof));
+        return w;
+    }
+    Stage0Response stage0_response_from_wire(const Bytes& b) const {
+        if (b.size() != 8 + 96 + 32) throw SerializationError("IoError: Stage0Response is 136 bytes");
+        Stage0Response r;
+        r.subcircuit_idx = get_u64(b.data());
+        r.com = points_from_wire(1, b.data() + 8, 1);
+        memcpy(r.com_seed.data(), b.data() + 104, 32);
+        return r;
+    }
+    Stage1Response stage1_response_from_wire(const Bytes& b) const {
+        if (b.size() < 8 + 96 + 192 + 96 + 8) throw SerializationError("IoError: unexpected end of input");
+        Stage1Response r;
+        const uint8_t* p = b.data();
+        r.subcircuit_idx = get_u64(p); p += 8;
+        r.proof.a = points_from_wire(1, p, 1); p += 96;
+        r.proof.b = points_from_wire(2, p, 1); p += 192;
+        r.proof.c = points_from_wire(1, p, 1); p += 96;
+        uint64_t nd = get_u64(p); p += 8;
+        if (b.size() != 8 + 96 + 192 + 96 + 8 + nd * 96) throw SerializationError("IoError: wrong length");
+        for (uint64_t i = 0; i < nd; i++, p += 96) r.proof.ds.push_back(points_from_wire(1, p, 1));
+        return r;
+    }
+
+private:
+    const Context& ctx_;
+};
+
+// `Fr::rand` on BLS12-381 Fr: four u64 limbs, the ONE bit above the 255-bit modulus cleared, accepted iff < r
+inline Bytes fr_rand_mont_bls12_381(ChaCha12Rng& rng) {
+    static const uint64_t r[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+    for (;;) {
+        uint64_t l[4];
+        for (int i = 0; i < 4; i++) l[i] = rng.next_u64();
+        l[3] &= ~0ull >> 1;
+        bool lt = false;
+        for (int i = 3; i >= 0; i--) if (l[i] != r[i]) { lt = l[i] < r[i]; break; }
+        if (!lt) continue;
+        Bytes out(32);
+        for (int i = 0; i < 4; i++) for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(l[i] >> (8 * b));
+        return out;
+    }
+}
+inline Bytes commitment_randomness_bls12_381(const std::array<uint8_t, 32>& com_seed) {
+    ChaCha12Rng rng(com_seed);
+    return fr_rand_mont_bls12_381(rng);
 }
 
 }  // namespace hekaton

@@ -1,4 +1,4 @@
-"""GPU: the native job driver (apps/hk_all_in_one.cpp: C++ host mirror + threads over the C ABI, the shape of
+"""GPU: the native job driver (apps/hk_all_in_one.cpp: C++ host mirror + threads over the C ABI, both curves, the shape of
 mpi-snark/src/bin/all_in_one.rs:109-196) on an 8-subcircuit, 5-class job: every Stage0Response / Stage1Response file it
 writes equals, byte for byte, the ark-serialize bytes of the Python worker path for the same subcircuit (same key, same
 assignment, kappa from the same com_seed, same r and s) - two independent host stacks over one library."""
@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_native_driver_writes_the_python_worker_bytes(tmp_path, ctx_bn254):
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_native_driver_writes_the_python_worker_bytes(cname, tmp_path, ctx_bn254, ctx_bls):
     from hekaton_system_amd.ark_serialize import ArkCodec
     from hekaton_system_amd.chacha import ChaCha12Rng
     from hekaton_system_amd.cp_groth16 import FrCodec, Proof
@@ -25,15 +26,19 @@ def test_native_driver_writes_the_python_worker_bytes(tmp_path, ctx_bn254):
     job, out = str(tmp_path / "job"), str(tmp_path / "out")
     os.makedirs(out)
     n = 8
-    reps, cls_of = export(job, "tiny", n, witnesses=2, ctx=ctx_bn254)
+    ctx0 = ctx_bn254 if cname == "bn254" else ctx_bls
+    reps, cls_of = export(job, "tiny", n, witnesses=2, ctx=ctx0, curve=cname)
     assert len(reps) == 5
-    res = subprocess.run([exe, job, out, "--threads", "4", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
-                         timeout=300)
+    res = subprocess.run([exe, job, out, "--threads", "4", "--steps", "2", "--warmup", "1", "--curve", cname],
+                         capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     line = json.loads(res.stdout.strip().splitlines()[-1])
-    assert line["subcircuits"] == n and line["classes"] == 5 and line["proofs_per_s"] > 0
+    assert line["subcircuits"] == n and line["classes"] == 5 and line["proofs_per_s"] > 0 and line["curve"] == cname
+    sizes = {"bn254": (104, 336), "bls12_381": (136, 496)}[cname]
+    assert (os.path.getsize(os.path.join(out, "stage0_resp_0.bin")), os.path.getsize(os.path.join(out, "stage1_resp_0.bin"))) == sizes
     # the same job through the Python host stack
-    ctx, fc, codec = ctx_bn254, FrCodec("bn254"), ArkCodec("bn254")
+    ctx, fc, codec = ctx0, FrCodec(cname), ArkCodec(cname)
+    frb = ctx.fr_bytes
     rd = lambda *p: np.fromfile(os.path.join(job, *p), np.uint8)
     subs = np.fromfile(os.path.join(job, "subs"), np.uint64).reshape(n, 2)
     keys = {}
@@ -54,7 +59,7 @@ def test_native_driver_writes_the_python_worker_bytes(tmp_path, ctx_bn254):
         seed = hashlib.sha256(b"com_seed %d" % i).digest()
         kappa = fc.enc1(ChaCha12Rng(seed).fr(fc.r))
         r_, s_ = (fc.enc1(int.from_bytes(hashlib.sha256(t % i).digest(), "little") % fc.r) for t in (b"r %d", b"s %d"))
-        com = dpk.commit(0, z[n_inst * 32:(n_inst + n0) * 32], kappa)
+        com = dpk.commit(0, z[n_inst * frb:(n_inst + n0) * frb], kappa)
         a, b, c = dpk.prove(z, r_, s_, kappa)
         want0 = codec.stage0_response_to_wire(Stage0Response(i, com, seed))
         want1 = codec.stage1_response_to_wire(Stage1Response(i, Proof(a, b, c, [com])))
@@ -64,5 +69,5 @@ def test_native_driver_writes_the_python_worker_bytes(tmp_path, ctx_bn254):
         dpk.free()
     # a job directory that lies about its size is refused, not indexed out of range
     np.array([n + 1, 5], np.uint64).tofile(os.path.join(job, "job"))
-    bad = subprocess.run([exe, job, out], capture_output=True, text=True, timeout=300)
+    bad = subprocess.run([exe, job, out, "--curve", cname], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 4 and "do not match" in bad.stderr

@@ -21,11 +21,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def export(job_dir, config="tiny", n=8, witnesses=2, single_class=False, ctx=None):
+def export(job_dir, config="tiny", n=8, witnesses=2, single_class=False, ctx=None, curve="bn254"):
     from hekaton_system_amd import capi
     from hekaton_system_amd.cp_groth16 import FrCodec, setup_device
     from hekaton_system_amd.workload import config_classes, prepare_class_host, representative_subcircuit
-    curve = "bn254"
     own = ctx is None
     ctx = ctx or capi.Context(curve, 0)
     fc = FrCodec(curve)
@@ -82,6 +81,7 @@ if __name__ == "__main__":
     ap.add_argument("--subcircuits", type=int, default=8)
     ap.add_argument("--witnesses", type=int, default=2)
     ap.add_argument("--single-class", action="store_true")
+    ap.add_argument("--curve", default="bn254")
     a = ap.parse_args()
-    reps, _ = export(a.job_dir, a.config, a.subcircuits, a.witnesses, a.single_class)
+    reps, _ = export(a.job_dir, a.config, a.subcircuits, a.witnesses, a.single_class, curve=a.curve)
     print("exported %d subcircuits, %d classes to %s" % (a.subcircuits, len(reps), a.job_dir))
