@@ -35,7 +35,10 @@ constexpr int MSM_MAX_LEVELS = 16;
 constexpr u32 MSM_LVL_L = HK_MSM_LVL_L;          // entries per lane on levels >= 1: 6 levels for a full 2^18-lane level 0 (8: 10 levels)
 constexpr int MSM_TAIL_THREADS = 256;  // levels whose lane count fits one workgroup run fused in k_msm_accum_tail
 constexpr int MSM_WSUM_THREADS = 256;
-constexpr int MSM_SORT_THREADS = 1024;
+#ifndef HK_MSM_SORT_THREADS
+#define HK_MSM_SORT_THREADS 1024
+#endif
+constexpr int MSM_SORT_THREADS = HK_MSM_SORT_THREADS;   // build-time knob
 // a sorted entry = sign << 31 | table group << gshift | scalar index, gshift = ceil(log2 n) <= 26 (so no division
 // in the accumulate loop); 31 - gshift bits hold the group: >= 5 bits at the largest n, where c >= 13 gives F <= 20,
 // and 64 groups (c = 4) only occur for n < 2^10
