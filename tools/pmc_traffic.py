@@ -21,8 +21,10 @@ out = {
     "FETCH_SIZE_KiB_H_launch": max(f), "WRITE_SIZE_KiB_H_launch": max(w), "launches": len(f),
     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (HK_SERIAL_STREAMS=1 bench.py --steps 1 "
             "--warmup 0 --subcircuits 2 --threads 1); *_avg = mean over all launches of the kernel (5 per subcircuit), "
-            "*_H_launch = the dense H-query launch. Random 64-B gathers: the gfx950 x2 FETCH_SIZE calibration for wide "
-            "coalesced streams is not established for this pattern, raw values quoted.",
+            "*_H_launch = the dense H-query launch.  Calibration for THIS access pattern (MI355X_MICROARCH.md, HBM: only wide "
+            "coalesced streams are known to read 1/2): the H launch REQUESTS (m-1) x 16 rows x 64 B + the 4-byte entries = "
+            "2.28 GB and the counter reads 2.57 GB, i.e. 1.13 x the requested bytes - 64-byte row gathers are tallied at "
+            "their size, so the raw values are quoted with no x2.",
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

@@ -17,7 +17,7 @@ python3 tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_writ
 python3 - <<PY
 import json
 d = json.load(open("$P/${R}_pmc_accum0.json"))
-out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, tools/pmc_traffic.py); per-launch averages of k_msm_accum0<Fp<...FqP>>, raw counter values (random 64-B gathers: no x2 calibration, see DESIGN.md section 4)",
+out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, tools/pmc_traffic.py); per-launch averages of k_msm_accum0<Fp<...FqP>>, raw counter values: for this pattern the counter reads 1.13 x the REQUESTED bytes on the H launch (2.57 GB against (m-1) x 16 rows x 64 B + entries = 2.28 GB), so the x2 correction of wide coalesced streams does not apply",
        "big-merkle-64x32/bn254": {"FETCH_SIZE_KiB_avg": d["FETCH_SIZE_KiB_avg"], "WRITE_SIZE_KiB_avg": d["WRITE_SIZE_KiB_avg"],
                                   "collected": "profiles/${R}_pmc_accum0.json"}}
 json.dump(out, open("$P/pmc_accum0.json", "w"), indent=1)
