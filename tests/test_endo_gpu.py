@@ -1,0 +1,85 @@
+"""GPU regression for round 2's psi(0, 0) anomaly: infinity lanes - at every position that matters
+inside and across wavefronts - go through psi (k_points_psi4), phi (k_points_phi2) and the negations both kernels apply,
+on BLS12-381 and BN254, THROUGH THE LIBRARY (hk_points_fold_g2 / hk_points_fold_g1), and come back as (0, 0) while every
+other lane equals the oracle's scalar multiple.  The first form of k_points_psi4 returned a launch-to-launch varying
+non-zero y for the (0, 0) lane on BLS12-381: a hipcc miscompile (a deleted copy in the else arm of the inlined
+`Fp::neg`), fenced at build time by tools/isa_lanecheck.py; this test is the run-time side of the fence."""
+import random
+
+import numpy as np
+import pytest
+
+from hekaton_system_amd.cp_groth16 import FrCodec
+from hekaton_system_amd.endo import phi2, psi4
+from oracle.pyref import curve
+from oracle.pyref.codec import Codec
+from oracle.pyref.params import CURVES
+
+pytestmark = pytest.mark.gpu
+
+INF_LANES = (0, 1, 31, 63, 64, 65, 69)          # first / last lane of a wavefront, the next wavefront, the tail
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "bn254"])
+def test_infinity_lanes_through_psi_and_its_negations(cname, ctx_bn254, ctx_bls):
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    cp, fc, cd = CURVES[cname], FrCodec(cname), Codec(CURVES[cname])
+    G2 = curve.G2(cp)
+    rnd = random.Random(77)
+    n = 70
+    g2b = ctx.g2_bytes
+    ks = [rnd.randrange(1, cp.r) for _ in range(n)]
+    hi = ctx.fixed_base(2, cd.g2_vec([cp.g2_gen]), fc.enc(ks)).copy()
+    for i in INF_LANES:
+        hi[i * g2b:(i + 1) * g2b] = 0
+    lo = np.zeros(n * g2b, dtype=np.uint8)                      # lo = O everywhere: the fold returns c * hi
+    pts = [None if i in INF_LANES else G2.mul(cp.g2_gen, ks[i]) for i in range(n)]
+    lam = psi4(cname).lam
+    # c = lam^j exercises psi^j alone; r - lam^j its negation (neg_mask bit j); a random c all four images at once
+    scalars = [1, lam, lam * lam % cp.r, pow(lam, 3, cp.r), cp.r - lam, cp.r - pow(lam, 3, cp.r), rnd.randrange(cp.r)]
+    first = {}
+    for rep in range(3):                                        # the wrong limb changed from launch to launch
+        for c in scalars:
+            got = ctx.points_fold_g2(lo, hi, c, n=n)
+            for i in range(n):
+                have = cd.g2_from(got[i * g2b:(i + 1) * g2b])
+                if i in INF_LANES:
+                    assert have is None, (cname, rep, c, i, "psi(O) must be O")
+                elif rep == 0 and (i < 3 or i in (62, 66)):     # oracle multiples are slow: a few lanes around the O lanes
+                    want = G2.mul(pts[i], c)
+                    assert have == (want[0], want[1]), (cname, c, i)
+            if rep:
+                assert np.array_equal(got, first[c]), (cname, rep, c, "not deterministic")
+            else:
+                first[c] = got.copy()
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "bn254"])
+def test_infinity_lanes_through_phi_and_its_negations(cname, ctx_bn254, ctx_bls):
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    cp, fc, cd = CURVES[cname], FrCodec(cname), Codec(CURVES[cname])
+    G1 = curve.G1(cp)
+    rnd = random.Random(78)
+    n = 70
+    g1b = ctx.g1_bytes
+    ks = [rnd.randrange(1, cp.r) for _ in range(n)]
+    hi = ctx.fixed_base(1, cd.g1_vec([cp.g1_gen]), fc.enc(ks)).copy()
+    for i in INF_LANES:
+        hi[i * g1b:(i + 1) * g1b] = 0
+    lo = np.zeros(n * g1b, dtype=np.uint8)
+    lam = phi2(cname).lam
+    first = {}
+    for rep in range(3):
+        for c in [1, lam, cp.r - 1, cp.r - lam, rnd.randrange(cp.r)]:
+            got = ctx.points_fold_g1(lo, hi, c, n=n)
+            for i in range(n):
+                have = cd.g1_from(got[i * g1b:(i + 1) * g1b])
+                if i in INF_LANES:
+                    assert have is None, (cname, rep, c, i, "phi(O) must be O")
+                elif rep == 0 and (i < 3 or i in (62, 66)):
+                    want = G1.mul(G1.mul(cp.g1_gen, ks[i]), c)
+                    assert have == (want[0], want[1]), (cname, c, i)
+            if rep:
+                assert np.array_equal(got, first[c]), (cname, rep, c, "not deterministic")
+            else:
+                first[c] = got.copy()

@@ -10,7 +10,9 @@ VGPRs / AGPRs, scratch bytes per lane (.private_segment_fixed_size), dynamic-sta
      above it hipcc's branch relaxation emits long jumps through `s_getpc_b64 s[30:31]` / `s_setpc_b64 s[30:31]` in
      leaf functions, i.e. through the function's own return address, which a leaf never saves;
   2. no `s_getpc_b64 s[30:31]` ... `s_setpc_b64 s[30:31]` sequence anywhere (the direct signature of that miscompile);
-  3. no kernel may use a dynamic stack or need more private memory per lane than SCRATCH_LIMIT_BYTES.
+  3. no kernel may use a dynamic stack or need more private memory per lane than SCRATCH_LIMIT_BYTES;
+  4. no "half-defined" VGPR read at the join of a divergent if / else (tools/isa_lanecheck.py: the signature of the
+     hipcc miscompile behind the psi(0, 0) anomaly of round 2).
 """
 import os
 import re
@@ -134,16 +136,24 @@ def main():
             bad.append("device function larger than the s_cbranch reach (%d B): %s" % (sz, n))
     if check and n_getpc:
         bad.append("%d long branch(es) through the return-address pair s[30:31]" % n_getpc)
+    n_lane = None
+    if check:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import isa_lanecheck
+        nfunc, hits = isa_lanecheck.run(files)
+        n_lane = len(hits)
+        for name, ins, P, S in hits[:20]:
+            bad.append("half-defined VGPR read at 0x%x (%s) in %s" % (ins.addr, ins.mn, name[:110]))
     if check and bad:
-        print("\nkernel_meta --check FAILED (dynamic stack, scratch > %d B per lane, oversized device function or "
-              "s[30:31] long branch):" % SCRATCH_LIMIT_BYTES, file=sys.stderr)
+        print("\nkernel_meta --check FAILED (dynamic stack, scratch > %d B per lane, oversized device function, "
+              "s[30:31] long branch or half-defined VGPR read):" % SCRATCH_LIMIT_BYTES, file=sys.stderr)
         for b in bad:
             print("  " + b[:200], file=sys.stderr)
         sys.exit(1)
     if check:
         print("kernel_meta --check ok: %d kernels, no dynamic stack, max scratch %d B per lane (limit %d), no device "
-              "function above the s_cbranch reach, no s[30:31] long branch" % (
-                  len(rows), max(r["scratch"] for r in rows), SCRATCH_LIMIT_BYTES))
+              "function above the s_cbranch reach, no s[30:31] long branch, no half-defined VGPR read at an if / else "
+              "join" % (len(rows), max(r["scratch"] for r in rows), SCRATCH_LIMIT_BYTES))
 
 
 if __name__ == "__main__":
