@@ -89,6 +89,9 @@ template <class F> static void parallel_for(size_t n, unsigned threads, F f) {
 }
 
 int main(int argc, char** argv) {
+    // before any thread exists and before the first HIP call: hardware queues for the concurrent proofs (the library
+    // itself never writes the environment); a value the user exported wins
+    setenv("GPU_MAX_HW_QUEUES", "20", 0);
     if (argc < 3) {
         fprintf(stderr, "usage: %s <job_dir> <out_dir> [--threads T] [--steps K] [--warmup W] [--device D] [--host-inputs] [--curve bn254|bls12_381]\n", argv[0]);
         return 2;

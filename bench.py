@@ -279,6 +279,7 @@ class Job:
         self.pool = ThreadPoolExecutor(max_workers=args.threads)
         self.accum_ms, self.accum_n, self.accum_h, self.phase = [], [], [], {}
         self.gather_s = 0.0
+        self.wait_s = 0.0
         self.wg_s = 0.0
         self.last_records = None
         self.prev_records = None
@@ -321,7 +322,14 @@ class Job:
         return time.time() - t0
 
     def _gather(self, records):
+        """The exchange step, timed in two parts: the wait for the slowest rank (a barrier of its own before the
+        collective - rank skew, not communication) and the all_gather itself."""
         from hekaton_system_amd.worker import gather_records
+        if self.world > 1 or getattr(self, "force_dist", False):
+            import torch.distributed as dist
+            tw = time.time()
+            dist.barrier()
+            self.wait_s += time.time() - tw
         t0 = time.time()
         if getattr(self, "force_dist", False):
             import torch
@@ -479,6 +487,7 @@ def timed_run(job, steps, warmup, barrier):
     for _ in range(warmup):
         job.step(False)
     job.gather_s = 0.0
+    job.wait_s = 0.0
     job.wg_s = 0.0
     barrier()
     t0 = time.time()
@@ -608,16 +617,24 @@ def main():
     dt = dt_local
     per_rank = [args.subcircuits * args.steps / dt_local]
     gather_ms = [job.gather_s / args.steps * 1e3]
+    wait_ms = [job.wait_s / args.steps * 1e3]
+    rank_ms = [dt_local / args.steps * 1e3]
+    rank_classes = [sorted(job.classes)]
     if use_dist:
         on = "cuda" if backend == "nccl" else "cpu"
         tt = torch.tensor([dt_local], dtype=torch.float64, device=on)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        mine = torch.tensor([per_rank[0], gather_ms[0]], dtype=torch.float64, device=on)
+        mine = torch.tensor([per_rank[0], gather_ms[0], wait_ms[0], rank_ms[0]], dtype=torch.float64, device=on)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [float(x[0]) for x in allr]
         gather_ms = [float(x[1]) for x in allr]
+        wait_ms = [float(x[2]) for x in allr]
+        rank_ms = [float(x[3]) for x in allr]
+        parts = [None] * world
+        dist.all_gather_object(parts, sorted(job.classes))
+        rank_classes = parts
     # the dominant kernel WITHOUT other proofs sharing the chip: three proofs one after another on one lane, after the
     # timed region (reported beside the timed-region figure, never instead of it)
     alone = []
@@ -669,7 +686,12 @@ def main():
                        "pk_classes_rank0": {str(k): len(v["members"]) for k, v in job.classes.items()},
                        "exchange": "2 all_gathers per step (104 B + 328 B records), %s" % (backend if world > 1 else "local")},
             "roofline": roof,
-            "per_rank_proofs_per_s": per_rank, "gather_ms_per_step": gather_ms,
+            "per_rank_proofs_per_s": per_rank,
+            # the two exchange steps of a job, per rank: `collective` is the time inside the all_gathers with every rank
+            # already there; `waiting_for_slowest_rank` is the barrier in front of them (rank skew: a rank with lighter
+            # proving-key classes finishes its round early and waits here - not communication)
+            "exchange_ms_per_step": {"collective": gather_ms, "waiting_for_slowest_rank": wait_ms},
+            "per_rank_ms_per_step": rank_ms, "per_rank_pk_classes": rank_classes,
             "witness_gen_ms_per_step": (job.wg_s / args.steps * 1e3) if args.witness_gen else None,
             "timed_proofs_check": checks,
             "end_to_end": e2e,

@@ -121,12 +121,24 @@ struct Ops {
     static hk_status gt_pow(hk_ctx*, const void*, const void*, size_t, void*);
     static hk_status wprog_run(hk_ctx*, const hk_wprog*, const uint32_t*, size_t, const uint32_t*, const void*, size_t, void*);
 
+    static size_t max_private_bytes() {
+        size_t m = MsmRun<Fq>::max_private_bytes();
+        size_t b = MsmRun<Fq2>::max_private_bytes();
+        if (b > m) m = b;
+        b = PairRun<typename Fq::Params>::max_private_bytes();
+        if (b > m) m = b;
+        b = finish_private_bytes();
+        return b > m ? b : m;
+    }
+    static size_t finish_private_bytes();      // prove_impl.cuh (k_finish)
+
     static const CurveOps* table() {
         static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
                                    &msm, &ntt, &witness_map, &pk_upload, &pk_free, &commit, &prove,
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
-                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb, &points_fold_g2, &points_fold_g1, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow};
+                                   sizeof(Fp12<typename Fq::Params>), &points_lincomb, &points_fold_g2, &points_fold_g1, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow,
+                                   &max_private_bytes};
         return &t;
     }
 };

@@ -1,7 +1,64 @@
 // hk_core.hip — context / lane management and the C ABI entry points (dispatch to per-curve code).
 #include "hk_internal.h"
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <atomic>
 
 namespace hk {
+
+// ---- scratch budget ------------------------------------------------------------------------
+// Measured on MI355X / ROCm 7.2 (tools/scratch_probe.hip, profiles/r03_scratch_probe.txt): a hardware queue that has
+// run a kernel with B bytes of private memory per lane keeps a ring of B x 64 lanes x (CUs x 32 wave slots) bytes for
+// as long as it lives - 1.49 GiB for the 3056-byte frame of k_msm_reduce_fused<Fp2<Bls381FqP>> - however few waves the
+// kernel launches; the rings of all queues share HSA_AMD_AGENT_INFO_SCRATCH_LIMIT_MAX (32 GiB).  Streams map onto at
+// most GPU_MAX_HW_QUEUES queues and any of them may end up running the curve's deepest kernel, so the bound that no
+// setting of HK_MAX_LANES / HK_SERIAL_STREAMS can break is   queues x ring(deepest frame) + reserve <= limit.
+static hsa_status_t scratch_limit_cb(hsa_agent_t a, void* data) {
+    hsa_device_type_t type;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU)
+        return HSA_STATUS_SUCCESS;
+    uint64_t mx = 0;
+    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_SCRATCH_LIMIT_MAX, &mx) == HSA_STATUS_SUCCESS && mx) {
+        uint64_t* best = (uint64_t*)data;
+        if (*best == 0 || mx < *best) *best = mx;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+static uint64_t scratch_limit_bytes() {
+    static const uint64_t v = [] {
+        uint64_t best = 0;
+        if (hsa_init() == HSA_STATUS_SUCCESS) {            // reference-counted; HIP holds its own reference
+            (void)hsa_iterate_agents(scratch_limit_cb, &best);
+            (void)hsa_shut_down();
+        }
+        return best ? best : (uint64_t)32 << 30;           // what this pool's MI355X report
+    }();
+    return v;
+}
+static std::atomic<size_t> g_deepest_frame{0};             // over every curve a context was created for in this process
+
+hk_status scratch_budget_check(const CurveOps* ops, const hipDeviceProp_t& prop) {
+    size_t frame = ops->max_private_bytes ? ops->max_private_bytes() : 0;
+    size_t prev = g_deepest_frame.load();
+    while (frame > prev && !g_deepest_frame.compare_exchange_weak(prev, frame)) {}
+    frame = g_deepest_frame.load();
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    uint64_t queues = q && atoi(q) > 0 ? (uint64_t)atoi(q) : 4;          // the HIP runtime's default
+    uint64_t slots = (uint64_t)prop.multiProcessorCount * (uint64_t)(prop.maxThreadsPerMultiProcessor / 64);
+    uint64_t ring = (uint64_t)frame * 64 * slots;
+    uint64_t limit = scratch_limit_bytes();
+    const uint64_t reserve = (uint64_t)1 << 30;                          // other users of the agent (RCCL, torch, rocprofv3)
+    if (queues * ring + reserve > limit) {
+        uint64_t fit = ring ? (limit - reserve) / ring : queues;
+        fprintf(stderr, "[hekaton] scratch budget: %llu hardware queues x %.2f GiB (deepest kernel frame %zu B per lane x 64 x "
+                        "%llu wave slots) + 1 GiB reserve exceeds the agent's scratch limit of %.1f GiB; export "
+                        "GPU_MAX_HW_QUEUES=%llu or less before the first HIP call%s\n",
+                (unsigned long long)queues, ring / 1073741824.0, frame, (unsigned long long)slots, limit / 1073741824.0,
+                (unsigned long long)fit, getenv("HK_PAIR_SERIAL") ? " (or unset HK_PAIR_SERIAL: its kernels carry the deepest frames)" : "");
+        return HK_ERR_DEVICE;
+    }
+    return HK_OK;
+}
 
 static thread_local hk_timings tl_last_timings = {};
 
@@ -109,12 +166,11 @@ hk_status hk_ctx_create(hk_curve curve, int device_id, hk_ctx** out) {
     if (!out) return HK_ERR_ARG;
     *out = nullptr;
     if (curve != HK_BN254 && curve != HK_BLS12_381) return HK_ERR_ARG;
-    // hk_prove forks four side streams per lane and several lanes run at once: let the runtime map them onto more
-    // hardware queues than its default of 4 (8 proofs in flight: 4 queues 90 proofs/s, 16: 121, 20-22: 124, 24+: 115;
-    // DESIGN.md section 5).  Read when the HIP runtime initialises, so this only takes effect if no HIP call was made
-    // before the first hk_ctx_create (a host that initialises HIP earlier exports it itself); never
-    // overrides a value the user set.
-    setenv("GPU_MAX_HW_QUEUES", "20", 0);
+    // Concurrent proofs want more hardware queues than the HIP runtime's default of 4 (GPU_MAX_HW_QUEUES=20: DESIGN.md
+    // section 5).  The runtime reads that variable when it initialises and the library does NOT touch the process
+    // environment (setenv is not safe against another thread's getenv in a multi-threaded host): the host exports it
+    // before its first HIP call - the bindings and drivers of this repository do (capi.py, apps/hk_all_in_one.cpp,
+    // INTEGRATION.md section 3).
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void)hipGetLastError();
@@ -130,10 +186,13 @@ hk_status hk_ctx_create(hk_curve curve, int device_id, hk_ctx** out) {
                 prop.gcnArchName);
         return HK_ERR_DEVICE;
     }
+    const hk::CurveOps* ops = curve == HK_BN254 ? curve_ops_bn254() : curve_ops_bls381();
+    // no environment setting may be able to exhaust the runtime's scratch pool (the abort of round 2): refuse here
+    HK_TRY(hk::scratch_budget_check(ops, prop));
     hk_ctx* c = new hk_ctx();
     c->curve = curve;
     c->device = device_id;
-    c->ops = curve == HK_BN254 ? curve_ops_bn254() : curve_ops_bls381();
+    c->ops = ops;
     memset(&c->last, 0, sizeof(c->last));
     const char* ml = getenv("HK_MAX_LANES");
     if (ml && atoi(ml) > 0) c->max_lanes = (size_t)atoi(ml);

@@ -506,8 +506,10 @@ k_msm_reduce_fused(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __re
     __syncthreads();
     for (u32 off = MSM_REDUCE_THREADS / 2; off >= 1; off >>= 1) {
         if (threadIdx.x < off) {
-            XYZZ<F> a = sh[threadIdx.x], b = sh[threadIdx.x + off];
-            sh[threadIdx.x] = ec_add_ni(a, b);
+            // operands stay in LDS (the out-of-line add takes references): two private copies of 384 B each less per
+            // lane for the 12-limb G2 flavour, i.e. a smaller scratch ring on every queue that runs this kernel
+            XYZZ<F> t = ec_add_ni(sh[threadIdx.x], sh[threadIdx.x + off]);
+            sh[threadIdx.x] = t;
         }
         __syncthreads();
     }
@@ -525,8 +527,10 @@ k_msm_reduce_fused(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __re
     __syncthreads();
     for (u32 off = MSM_REDUCE_THREADS / 2; off >= 1; off >>= 1) {
         if (threadIdx.x < off) {
-            XYZZ<F> a = sh[threadIdx.x], b = sh[threadIdx.x + off];
-            sh[threadIdx.x] = ec_add_ni(a, b);
+            // operands stay in LDS (the out-of-line add takes references): two private copies of 384 B each less per
+            // lane for the 12-limb G2 flavour, i.e. a smaller scratch ring on every queue that runs this kernel
+            XYZZ<F> t = ec_add_ni(sh[threadIdx.x], sh[threadIdx.x + off]);
+            sh[threadIdx.x] = t;
         }
         __syncthreads();
     }
@@ -546,8 +550,10 @@ k_msm_window_sum(const XYZZ<F>* __restrict__ in, MsmPlan p, XYZZ<F>* __restrict_
     __syncthreads();
     for (u32 off = MSM_WSUM_THREADS / 2; off >= 1; off >>= 1) {
         if (threadIdx.x < off) {
-            XYZZ<F> a = sh[threadIdx.x], b = sh[threadIdx.x + off];
-            sh[threadIdx.x] = ec_add_ni(a, b);
+            // operands stay in LDS (the out-of-line add takes references): two private copies of 384 B each less per
+            // lane for the 12-limb G2 flavour, i.e. a smaller scratch ring on every queue that runs this kernel
+            XYZZ<F> t = ec_add_ni(sh[threadIdx.x], sh[threadIdx.x + off]);
+            sh[threadIdx.x] = t;
         }
         __syncthreads();
     }

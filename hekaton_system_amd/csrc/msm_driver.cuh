@@ -8,6 +8,13 @@
 
 namespace hk {
 
+// private-memory ("scratch") bytes per lane of a kernel, as the loaded code object declares them
+static inline size_t hk_private_bytes_of(const void* kernel) {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return (size_t)fa.localSizeBytes;
+}
+
 struct SortBufs {        // device buffers produced by the counting sort
     u32* count;          // [NB]
     u32* start;          // [NB + 1]   start[NB] = number of non-zero digits E
@@ -52,6 +59,9 @@ struct MsmRun {
     // out[i] = sum_j coeffs[j] * vecs[j][i], k <= LINCOMB_MAX (aggregation.rs:192-203,293-326)
     static hk_status lincomb(hipStream_t s, const Affine<F>* const* vecs, const void* coeffs_mont, u32 k, u32 n,
                              XYZZ<F>* xy, F* pref, Affine<F>* out);
+    // largest private-memory ("scratch") frame per lane among this flavour's kernels, from the loaded code object
+    // (hipFuncGetAttributes): what sizes a hardware queue's scratch ring
+    static size_t max_private_bytes();
 };
 
 // multi-pairing launch sequence (pairing.cuh); explicit instantiation in hk_<curve>_pair.hip
@@ -62,6 +72,8 @@ struct PairRun {
     static hk_status run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<Fp2<P>>* g2, u32 n, u32 n_l, u32 n_r,
                          Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out);
     static size_t scratch_bytes(u32 n, u32 count);
+    static size_t max_private_bytes();   // as MsmRun<F>::max_private_bytes, over the pairing / endomorphism kernels
+    static u32 steps();          // line-evaluation steps of the Miller loop (the factor of `count` in the tree launches' grid.y)
     // out[e] = in[e]^scalars[e] (GT powers; device pointers)
     static hk_status gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out);
     // out[j][i] = (neg_mask bit j ? - : +) psi^j(pts[i]), j = 0..3 (device pointers; G2 endomorphism, pairing.cuh g2_psi)

@@ -121,6 +121,21 @@ hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p0, const Affine<F>* tabl
     return HK_OK;
 }
 
+
+template <class F>
+size_t MsmRun<F>::max_private_bytes() {
+    typedef typename ScalarOf<F>::type Fr;
+    const void* ks[] = {(const void*)k_msm_accum0<F>, (const void*)k_msm_accum_lvl<F>, (const void*)k_msm_accum_tail<F>,
+                        (const void*)k_msm_reduce_fused<F>, (const void*)k_msm_bucket_reduce<F>,
+                        (const void*)k_msm_window_sum<F>, (const void*)k_msm_final<F>, (const void*)k_to_affine<F>,
+                        (const void*)k_msm_build_tables<F>, (const void*)k_batch_affine<F>, (const void*)k_fb_table<F>,
+                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>,
+                        (const void*)k_points_lincomb<Fr, F>};
+    size_t m = 0;
+    for (const void* k : ks) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }
+    return m;
+}
+
 template <class F>
 hk_status MsmRun<F>::build_tables(hipStream_t s, Affine<F>* table, u32 n, u32 groups, u32 shift_bits) {
     if (groups <= 1 || n == 0) return HK_OK;

@@ -43,6 +43,24 @@ hk_status PairRun<P>::psi4(hipStream_t s, const Affine<Fp2<P>>* pts, u32 n, u32 
 }
 
 template <class P>
+size_t PairRun<P>::max_private_bytes() {
+    const void* ks[] = {(const void*)k_pair_lines<P>, (const void*)k_pair_tree_lines<P>, (const void*)k_pair_tree<P>,
+                        (const void*)k_pair_horner<P>, (const void*)k_points_psi4<P>, (const void*)k_points_phi2<P>,
+                        (const void*)k_gt_pow<P, typename ScalarOfQ<P>::type>};
+    const void* serial[] = {(const void*)k_pair_miller<P>, (const void*)k_f12_product<P>, (const void*)k_final_exp<P>};
+    size_t m = 0;
+    for (const void* k : ks) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }
+    if (getenv("HK_PAIR_SERIAL"))            // the one-lane-per-pair debugging path carries the deepest frames (5 KB)
+        for (const void* k : serial) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }
+    return m;
+}
+
+template <class P>
+u32 PairRun<P>::steps() {
+    return (u32)pair_steps(PairLoopOf<P>::get(), TowerParams<P>::TWIST_IS_D).n;
+}
+
+template <class P>
 size_t PairRun<P>::scratch_bytes(u32 n, u32 count) {
     PairSteps st = pair_steps(PairLoopOf<P>::get(), TowerParams<P>::TWIST_IS_D);
     size_t S = (size_t)st.n, g0 = (n + 15) / 16;

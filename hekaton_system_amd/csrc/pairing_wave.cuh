@@ -166,12 +166,22 @@ struct WaveF12 {
         a[6] = f.c1.c0.c0; a[7] = f.c1.c0.c1; a[8] = f.c1.c1.c0; a[9] = f.c1.c1.c1; a[10] = f.c1.c2.c0; a[11] = f.c1.c2.c1;
         a[12] = Fq::zero();
     }
-    static __device__ __noinline__ void inv(Fq* dst, const Fq* a) {
+    // dst = a^-1 = conj(a) * (a * conj(a))^-1.  The norm a * conj(a) lies in Fq6 (its w-part is zero), so the part that
+    // runs on ONE lane inverts a 6-coefficient value: the by-value Fq12 temporaries of f12_inv (3.1 KB of private memory
+    // per lane on BLS12-381 - the deepest frame of the default path, and the frame sizes the scratch ring of every
+    // hardware queue) become two more wave products.  tmp: one scratch slot; dst, a, tmp distinct.
+    static __device__ __noinline__ void inv(Fq* dst, const Fq* a, Fq* tmp, WaveArea<P>* w) {
+        conj(tmp, a);
+        mul(dst, a, tmp, w);                     // the norm: coefficients 0..5
         if (threadIdx.x == 0) {
-            Fp12<P> f = f12_inv(load_tower(a));
-            store_tower(dst, f);
+            Fp6<P> n;
+            n.c0.c0 = dst[0]; n.c0.c1 = dst[1]; n.c1.c0 = dst[2]; n.c1.c1 = dst[3]; n.c2.c0 = dst[4]; n.c2.c1 = dst[5];
+            Fp6<P> ni = f6_inv(n);
+            dst[0] = ni.c0.c0; dst[1] = ni.c0.c1; dst[2] = ni.c1.c0; dst[3] = ni.c1.c1; dst[4] = ni.c2.c0; dst[5] = ni.c2.c1;
+            for (int k = 6; k < 13; k++) dst[k] = Fq::zero();
         }
         sync();
+        mul(dst, tmp, dst, w);                   // conj(a) * norm^-1
     }
     // dst = a^X (X = the curve parameter); t: one scratch slot.  dst, a, t distinct.
     static __device__ __noinline__ void pow_x(Fq* dst, const Fq* a, WaveArea<P>* w) {
@@ -198,7 +208,7 @@ struct WaveF12 {
         typedef TowerParams<P> TP;
         auto S = [&](int i) { return s + i * WV_SLOT; };
         Fq *r = S(0), *t = S(7), *u = S(8);
-        inv(t, r);                       // f^-1
+        inv(t, r, u, w);                 // f^-1
         conj(u, r);
         mul(r, u, t, w);                 // f^(q^6 - 1)
         frob<2>(t, r);

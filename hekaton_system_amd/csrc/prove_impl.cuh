@@ -1077,11 +1077,15 @@ hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n
     typedef typename Fq::Params P;
     typedef Fp12<P> GT;
     size_t count = n_lhs * n_rhs;
-    if (count == 0 || count > 4096) return HK_ERR_ARG;
+    if (count == 0 || count > 4096 || !out) return HK_ERR_ARG;
     if (n * count >= ((size_t)1 << 31)) return HK_ERR_ARG;
+    // the per-step product trees run as grid (groups, count * steps): grid.y is a 16-bit quantity
+    if (count * PairRun<P>::steps() > 65535) return HK_ERR_ARG;
     if (n == 0) {                                                  // empty product: 1 (final_exponentiation(1) = 1)
         GT one = f12_one<P>();
-        for (size_t k = 0; k < count; k++) memcpy((char*)out + k * sizeof(GT), &one, sizeof(GT));
+        HK_HIP(hipSetDevice(ctx->device));
+        for (size_t k = 0; k < count; k++)                        // `out` may be a device pointer, as on the n > 0 path
+            HK_HIP(hipMemcpy((char*)out + k * sizeof(GT), &one, sizeof(GT), is_device_ptr(out) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
         return HK_OK;
     }
     for (size_t a = 0; a < n_lhs; a++) if (!lhs[a]) return HK_ERR_ARG;
@@ -1243,6 +1247,11 @@ __global__ void k_finish(const XYZZ<Fq>* __restrict__ res_g1,   // MA, MB1, ML, 
         Cc = ec_add_ni(Cc, ld_vec(&res_g1[3]));
         st_vec(out_c, ec_to_affine(Cc));
     }
+}
+
+template <class C>
+size_t Ops<C>::finish_private_bytes() {
+    return hk_private_bytes_of((const void*)k_finish<Fr, Fq, Fq2>);
 }
 
 static inline float ev_ms(hipEvent_t a, hipEvent_t b) {

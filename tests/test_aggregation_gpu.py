@@ -19,13 +19,14 @@ from hekaton_system_amd.cp_groth16 import FrCodec, Proof, SeededRng, generate_pa
 from hekaton_system_amd.workload import config_classes, make_config, representative_subcircuit
 from oracle.pyref import curve, pairing
 from oracle.pyref.codec import Codec
-from oracle.pyref.params import BN254
+from oracle.pyref.params import CURVES
 
 pytestmark = pytest.mark.gpu
 
 
-def test_aggregation_front_half_on_real_proofs(ctx_bn254):
-    ctx, cname, cp = ctx_bn254, "bn254", BN254
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_aggregation_front_half_on_real_proofs(cname, ctx_bn254, ctx_bls):
+    ctx, cp = (ctx_bn254 if cname == "bn254" else ctx_bls), CURVES[cname]
     fc = FrCodec(cname)
     cd = Codec(cp)
     T = pairing.tower(cname)

@@ -26,8 +26,9 @@ from hekaton_system_amd.sha_circuit import ShaMerkleJob
 pytestmark = pytest.mark.gpu
 
 
-def test_whole_job_commit_prove_aggregate_verify(ctx_bn254):
-    ctx, cname = ctx_bn254, "bn254"
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_whole_job_commit_prove_aggregate_verify(cname, ctx_bn254, ctx_bls):
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
     r = CURVE_PARAMS[cname]["r"]
     fc = FrCodec(cname)
     n, ns, n_portals = 8, 1, 4

@@ -69,8 +69,9 @@ def test_infinity_lanes_through_phi_and_its_negations(cname, ctx_bn254, ctx_bls)
     lo = np.zeros(n * g1b, dtype=np.uint8)
     lam = phi2(cname).lam
     first = {}
+    scalars = [1, lam, cp.r - 1, cp.r - lam, rnd.randrange(cp.r)]
     for rep in range(3):
-        for c in [1, lam, cp.r - 1, cp.r - lam, rnd.randrange(cp.r)]:
+        for c in scalars:
             got = ctx.points_fold_g1(lo, hi, c, n=n)
             for i in range(n):
                 have = cd.g1_from(got[i * g1b:(i + 1) * g1b])

@@ -13,13 +13,14 @@ from hekaton_system_amd.cp_groth16 import FrCodec, Proof, SeededRng, generate_pa
 from hekaton_system_amd.workload import config_classes, make_config, representative_subcircuit
 from oracle.pyref import curve
 from oracle.pyref.codec import Codec
-from oracle.pyref.params import BN254
+from oracle.pyref.params import CURVES
 
 pytestmark = pytest.mark.gpu
 
 
-def test_tipp_closes_the_aggregation_of_real_proofs(ctx_bn254):
-    ctx, cname, cp = ctx_bn254, "bn254", BN254
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_tipp_closes_the_aggregation_of_real_proofs(cname, ctx_bn254, ctx_bls):
+    ctx, cp = (ctx_bn254 if cname == "bn254" else ctx_bls), CURVES[cname]
     fc = FrCodec(cname)
     cd = Codec(cp)
     family, n, reps = config_classes("tiny")
@@ -96,12 +97,13 @@ def test_tipp_closes_the_aggregation_of_real_proofs(ctx_bn254):
         rb.free()
 
 
-def test_agg_subcircuit_proofs_end_to_end_with_the_merlin_transcript(ctx_bn254):
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_agg_subcircuit_proofs_end_to_end_with_the_merlin_transcript(cname, ctx_bn254, ctx_bls):
     """aggregation.rs:138-345 whole, challenges from a merlin transcript with the label the reference's e2e test uses
     (coordinator.rs:411): prove, self-verify, and the verifier - re-deriving twist, s, t from the SAME public values -
     accepts; a transcript with another label derives other challenges and the instance no longer matches."""
     from hekaton_system_amd.merlin import Transcript as Merlin
-    ctx, cname, cp = ctx_bn254, "bn254", BN254
+    ctx, cp = (ctx_bn254 if cname == "bn254" else ctx_bls), CURVES[cname]
     fc = FrCodec(cname)
     family, n, reps = config_classes("tiny")
     rnd = random.Random(5)

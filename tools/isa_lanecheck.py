@@ -219,7 +219,11 @@ def analyse(name, insns, is_kernel, verbose=False, report_all=False):
             for d in range(len(stack) - 1, -1, -1):
                 if ops[1] in stack[d][2]:
                     has_else.add(stack[d][0])
-                    return stack[:d] + ((stack[d][0], "E", (ops[0],)),)
+                    # s_andn2_saveexec: EXEC = the else lanes at once.  s_or_saveexec: EXEC = then + else lanes (the whole
+                    # enclosing region) until the `s_xor_b64 exec, exec, D` that follows - writes in between reach every
+                    # lane of the parent, so the region is "pending" ("P": not part of an instruction's path) until then
+                    arm = "E" if mn == "s_andn2_saveexec_b64" else "P"
+                    return stack[:d] + ((stack[d][0], arm, (ops[0],)),)
             return stack
         if mn == "s_or_b64" and len(ops) == 3 and ops[0] == "exec" and ops[1] == "exec":
             for d in range(len(stack) - 1, -1, -1):
@@ -239,8 +243,8 @@ def analyse(name, insns, is_kernel, verbose=False, report_all=False):
             return stack + ((-1, "W", (ops[0],)),)
         if mn in ("s_and_b64", "s_andn2_b64", "s_xor_b64") and len(ops) == 3 and ops[0] == "exec" and "exec" in ops[1:]:
             other = ops[2] if ops[1] == "exec" else ops[1]
-            if mn == "s_xor_b64" and stack and stack[-1][1] == "E" and other in stack[-1][2]:
-                return stack                                     # second half of the else lowering (s_or_saveexec + s_xor)
+            if mn == "s_xor_b64" and stack and stack[-1][1] == "P" and other in stack[-1][2]:
+                return stack[:-1] + ((stack[-1][0], "E", stack[-1][2]),)     # second half of the else lowering
             # EXEC narrowed to a lane set this analysis cannot name (a mask collected inside arms, a loop's live lanes):
             # reads below it are never reported
             key = ("u", ins.addr)
@@ -255,7 +259,7 @@ def analyse(name, insns, is_kernel, verbose=False, report_all=False):
         stack = entry_stack[b]
         s, e = blocks[b]
         for i in range(s, e):
-            ins_path[i] = tuple((x[0], x[1]) for x in stack)
+            ins_path[i] = tuple((x[0], x[1]) for x in stack if x[1] != "P")
             stack = step(stack, i)
         for t in succ[b]:
             if t not in entry_stack:

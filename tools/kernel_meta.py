@@ -30,6 +30,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # frames cost launch latency, not correctness (the round-1 faults were NOT scratch).  8 KB is the
 # fence against an accidental fully-inlined frame.
 SCRATCH_LIMIT_BYTES = 8192
+# Scratch budget of the DEFAULT configuration (the library enforces the same bound at run time in
+# hk_ctx_create with the box's own numbers): every hardware queue that has run a kernel keeps a ring of frame x 64 lanes x
+# (256 CUs x 32 wave slots) bytes, the rings share the agent's 32 GiB, the bindings export GPU_MAX_HW_QUEUES=20.
+# Kernels reachable only with HK_PAIR_SERIAL=1 (the one-lane-per-pair debugging path) are not on the default path.
+SCRATCH_AGENT_LIMIT = 32 << 30
+SCRATCH_RESERVE = 1 << 30
+DEFAULT_HW_QUEUES = 20
+WAVE_SLOTS = 256 * 32
+SERIAL_ONLY = ("k_pair_miller", "k_f12_product", "k_final_exp")
 BRANCH_REACH_BYTES = 32767 * 4      # s_cbranch_*: signed 16-bit dword offset
 
 
@@ -136,6 +145,16 @@ def main():
             bad.append("device function larger than the s_cbranch reach (%d B): %s" % (sz, n))
     if check and n_getpc:
         bad.append("%d long branch(es) through the return-address pair s[30:31]" % n_getpc)
+    deep = max((r for r in rows if not any(k in dm[r["symbol"]] for k in SERIAL_ONLY)), key=lambda r: r["scratch"], default=None)
+    if deep:
+        ring = deep["scratch"] * 64 * WAVE_SLOTS
+        need = DEFAULT_HW_QUEUES * ring + SCRATCH_RESERVE
+        print("scratch budget of the default configuration: deepest default-path frame %d B (%s) -> ring %.2f GiB per queue; "
+              "%d queues + reserve = %.1f GiB of %d GiB" % (deep["scratch"], re.sub(r"\(.*", "", dm[deep["symbol"]])[:60], ring / 2**30,
+                                                           DEFAULT_HW_QUEUES, need / 2**30, SCRATCH_AGENT_LIMIT >> 30))
+        if check and need > SCRATCH_AGENT_LIMIT:
+            bad.append("scratch budget: %d queues x %.2f GiB + reserve exceed the agent's %d GiB (frame %d B in %s)" % (
+                DEFAULT_HW_QUEUES, ring / 2**30, SCRATCH_AGENT_LIMIT >> 30, deep["scratch"], dm[deep["symbol"]][:80]))
     n_lane = None
     if check:
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
