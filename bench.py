@@ -61,6 +61,10 @@ def parse():
                          "of the rank's shard resident and picks by the reference's index -> class map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the BLS12-381 secondary measurement (N = 1 only)")
+    ap.add_argument("--no-synthesis-leg", action="store_true",
+                    help="skip the `with_synthesis` object (N = 1 only): real SHA-256 big-merkle subcircuits whose "
+                         "assignments are generated INSIDE the timed step - the reference's timer includes synthesis "
+                         "(node.rs:589-596, prover.rs:70-75)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing checks of the timed proofs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the post-timing aggregation of the last step's proofs")
     ap.add_argument("--witness-gen", action="store_true",
@@ -243,10 +247,14 @@ class Job:
             if args.witness_gen:
                 # the requests of this rank's subcircuits (leaf bytes / child hashes / portal entries: INPUT data, made
                 # before the timed region) and the class's word program on the device
+                from hekaton_system_amd.poseidon import device_params
                 from hekaton_system_amd.sha_circuit import example_witness, program_inputs
                 ws = [example_witness(circ, seed=seeds[pos % len(seeds)], entry_chal=0x1234567, tr_chal=0x7654321)
                       for pos in range(len(members))]
                 ops, refs, vmap = circ.tape.word_program(circ.n_v)
+                if not hasattr(self, "poseidon_params"):
+                    pp = device_params(curve, self.fc)
+                    self.poseidon_params = (capi.DeviceBuffer.from_host(self.ctx, pp[0]),) + pp[1:]
                 extra = dict(wg_ws=ws, wg_inputs=program_inputs(circ, ws),
                              wprog=self.ctx.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs),
                              zbig=capi.DeviceBuffer(self.ctx, len(members) * circ.n_v * self.ctx.fr_bytes))
@@ -309,15 +317,21 @@ class Job:
         return Stage1Response(i, Proof(a, b, cc, [com])).to_record(), t
 
     def _generate_witnesses(self):
-        """Stage-1 witness generation for every subcircuit of the shard, one batched hk_wprog_run per proving-key class
-        (classes run concurrently): the host computes each subcircuit's ~40 full-width values (running evaluations),
-        the device everything else."""
-        from hekaton_system_amd.sha_circuit import full_values
+        """Stage-1 witness generation for every subcircuit of the shard, one batched hk_wprog_run + hk_poseidon_path per
+        proving-key class (classes run concurrently): the host computes each subcircuit's ~50 full-width values (portal
+        entries, running evaluations, address-step flags), the device everything else (the SHA-256 chains' bits, the
+        Poseidon membership block)."""
+        from hekaton_system_amd.sha_circuit import full_values, poseidon_inputs
         t0 = time.time()
 
         def one(c):
-            cols, vals = full_values(c["circ"], c["wg_ws"])
+            circ = c["circ"]
+            cols, vals = full_values(circ, c["wg_ws"])
             c["wprog"].run(c["wg_inputs"], cols, vals, out=c["zbig"])
+            # the membership block (execution-tree leaf hash + path, subcircuit_circuit.rs:233-252) from the request's
+            # leaf and path, computed on the device into the same assignments
+            leaves, sibs, idx = poseidon_inputs(circ, c["wg_ws"])
+            self.ctx.poseidon_path(self.poseidon_params, leaves, sibs, idx, circ.n_v, circ.pos_col0, c["zbig"])
         list(self.pool.map(one, list(self.classes.values())))
         return time.time() - t0
 
@@ -585,6 +599,14 @@ def main():
     want_secondary = rank == 0 and world == 1 and not args.no_secondary and args.curve == "bn254"
     prep = prepare_job_host(args, args.curve, rank, world, single_class=args.single_class)
     prep2 = prepare_job_host(args, "bls12_381", 0, 1, single_class=True, witnesses=2) if want_secondary else None
+    # third leg: the same job shape on REAL SHA-256 subcircuits with every stage-1 assignment generated inside the step
+    want_synth = (rank == 0 and world == 1 and not args.no_synthesis_leg and args.curve == "bn254"
+                  and args.config == "big-merkle-64x32" and not args.witness_gen and args.subcircuits == 64)
+    args3 = prep3 = None
+    if want_synth:
+        args3 = argparse.Namespace(**vars(args))
+        args3.config, args3.witness_gen, args3.host_inputs = "big-merkle-sha-64x32", True, False
+        prep3 = prepare_job_host(args3, "bn254", 0, 1)
     from hekaton_system_amd import capi          # noqa: F401  first: exports GPU_MAX_HW_QUEUES before HIP initialises
     import torch
     import torch.distributed as dist
@@ -722,6 +744,30 @@ def main():
             except Exception as e:       # noqa: BLE001
                 log("secondary (BLS12-381) run failed:", repr(e))
                 out["secondary"] = None
+        if want_synth:
+            try:
+                if job is not None:
+                    job.close()
+                    job = None
+                j3 = Job(args3, prep3, 0, 1, dev, backend)
+                s3 = max(2, min(args.steps, 4))
+                dt3 = timed_run(j3, s3, 1, barrier)
+                chk3 = None if args.no_verify else j3.verify_last_step()
+                c3 = j3.circ
+                out["with_synthesis"] = {
+                    "workload": "big-merkle-sha-64x32: 64 real SHA-256 big-merkle subcircuits (32 iterations, 5 proving-key "
+                                "classes, own gadget set - DESIGN.md section 4c), every stage-1 assignment generated on the "
+                                "GPU inside the step from the subcircuit's inputs (the reference times synthesis inside "
+                                "stage 1: node.rs:589-596, prover.rs:70-75)",
+                    "curve": "bn254", "value": args.subcircuits * s3 / dt3, "unit": "proofs/s", "steps": s3, "warmup": 1,
+                    "ms_per_step": dt3 / s3 * 1e3, "witness_gen_ms_per_step": j3.wg_s / s3 * 1e3,
+                    "n_constraints": c3.n_c, "n_variables": c3.n_v,
+                    "pk_classes": {str(k): len(v["members"]) for k, v in j3.classes.items()},
+                    "timed_proofs_check": chk3}
+                j3.close()
+            except Exception as e:       # noqa: BLE001
+                log("with_synthesis (real SHA-256, witness generation in the step) run failed:", repr(e))
+                out["with_synthesis"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if job is not None:
         job.close()

@@ -28,6 +28,11 @@ class HekatonError(RuntimeError):
         super().__init__("%s failed: %s" % (what, status_str(status)))
 
 
+class hk_poseidon_desc(C.Structure):          # include/hekaton.h
+    _fields_ = [("t", C.c_uint32), ("alpha", C.c_uint32), ("full_rounds", C.c_uint32), ("partial_rounds", C.c_uint32),
+                ("consts_offset", C.c_uint32)]
+
+
 class hk_csr(C.Structure):
     _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("val_mont", C.c_void_p),
                 ("n_rows", C.c_size_t), ("nnz", C.c_size_t)]
@@ -62,7 +67,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_poseidon_path"]
 
 _lib = None
 
@@ -121,6 +126,8 @@ def load():
         lib.hk_wprog_run.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
     if hasattr(lib, "hk_gt_pow"):
         lib.hk_gt_pow.argtypes = [vp, vp, vp, sz, vp]
+    lib.hk_poseidon_path.argtypes = [vp, vp, sz, C.POINTER(hk_poseidon_desc), C.POINTER(hk_poseidon_desc), vp, vp, vp, sz, sz,
+                                     sz, sz, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
                                    vp, sz, vp, sz, C.POINTER(sz)]
     lib.hk_pk_upload.argtypes = [vp, C.POINTER(hk_pk_desc), C.POINTER(vp)]
@@ -350,6 +357,23 @@ class Context:
                                                vals.ctypes.data if cols.size else None, cols.size, buf.ptr),
               "hk_assignment_from_bits")
         return buf
+
+    def poseidon_path(self, params, leaf, siblings, index, n_v, col0, z_out):
+        """hk_poseidon_path: the membership block of `batch` assignments, written on the device.  params:
+        (consts DeviceBuffer or Montgomery bytes, n_consts, (t, alpha, rf, rp, off) of the leaf hash, same of the node hash)
+        - poseidon.device_params(curve); leaf: Montgomery bytes (batch, 4 Fr); siblings: (batch, depth Fr); index: uint32
+        (batch); z_out: DeviceBuffer (or raw device address) of batch x n_v Fr."""
+        consts, n_consts, ld, nd = params
+        leaf = np.ascontiguousarray(leaf, dtype=np.uint8)
+        batch = leaf.shape[0]
+        siblings = np.ascontiguousarray(siblings, dtype=np.uint8).reshape(batch, -1)
+        depth = siblings.shape[1] // self.fr_bytes
+        index = np.ascontiguousarray(index, dtype=np.uint32)
+        a, b = hk_poseidon_desc(*ld), hk_poseidon_desc(*nd)
+        zp = z_out.ptr if isinstance(z_out, DeviceBuffer) else int(z_out)
+        check(self.lib.hk_poseidon_path(self.handle, ptr(consts), int(n_consts), C.byref(a), C.byref(b), leaf.ctypes.data,
+                                        siblings.ctypes.data if depth else None, index.ctypes.data, depth, batch, int(n_v),
+                                        int(col0), zp), "hk_poseidon_path")
 
     def wprog_upload(self, ops, refs, vmap, n_values, n_inputs):
         """hk_wprog_upload: a class's word program (sha_circuit.Tape.word_program) resident on the device."""

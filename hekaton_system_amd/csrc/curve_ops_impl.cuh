@@ -131,6 +131,8 @@ struct Ops {
         return b > m ? b : m;
     }
     static size_t finish_private_bytes();      // prove_impl.cuh (k_finish)
+    static hk_status poseidon_path(hk_ctx*, const void*, size_t, const hk_poseidon_desc*, const hk_poseidon_desc*, const void*,
+                                   const void*, const uint32_t*, size_t, size_t, size_t, size_t, void*);
 
     static const CurveOps* table() {
         static const CurveOps t = {sizeof(Fr), sizeof(Fq), sizeof(Affine<Fq>), sizeof(Affine<Fq2>),
@@ -138,7 +140,7 @@ struct Ops {
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
                                    sizeof(Fp12<typename Fq::Params>), &points_lincomb, &points_fold_g2, &points_fold_g1, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow,
-                                   &max_private_bytes};
+                                   &max_private_bytes, &poseidon_path};
         return &t;
     }
 };

@@ -320,6 +320,13 @@ hk_status hk_wprog_upload(hk_ctx* ctx, const uint32_t* ops, size_t n_ops, const 
 void hk_wprog_free(hk_wprog* w) {
     if (w) w->ops->wprog_free(w);
 }
+hk_status hk_poseidon_path(hk_ctx* ctx, const void* consts_mont, size_t n_consts, const hk_poseidon_desc* leaf_hash,
+                           const hk_poseidon_desc* node_hash, const void* leaf_mont, const void* siblings_mont,
+                           const uint32_t* leaf_index, size_t depth, size_t batch, size_t n_v, size_t col0, void* z_out) {
+    if (!ctx) return HK_ERR_ARG;
+    return ctx->ops->poseidon_path(ctx, consts_mont, n_consts, leaf_hash, node_hash, leaf_mont, siblings_mont, leaf_index,
+                                   depth, batch, n_v, col0, z_out);
+}
 hk_status hk_wprog_run(hk_ctx* ctx, const hk_wprog* w, const uint32_t* inputs, size_t batch, const uint32_t* full_cols,
                        const void* full_vals_mont, size_t n_full, void* z_out) {
     if (!ctx || !w || w->ctx != ctx || !z_out || (batch && !inputs) || (n_full && (!full_cols || !full_vals_mont))) return HK_ERR_ARG;

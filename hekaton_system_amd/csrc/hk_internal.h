@@ -129,6 +129,9 @@ struct CurveOps {
     // largest private-memory frame (bytes per lane) among the curve's kernels: sizes the scratch ring the runtime
     // pins to every hardware queue that ever runs one of them
     size_t (*max_private_bytes)();
+    hk_status (*poseidon_path)(hk_ctx*, const void* consts, size_t n_consts, const hk_poseidon_desc* leaf_hash,
+                               const hk_poseidon_desc* node_hash, const void* leaf, const void* siblings,
+                               const uint32_t* index, size_t depth, size_t batch, size_t n_v, size_t col0, void* z_out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

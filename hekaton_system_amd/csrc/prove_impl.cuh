@@ -1070,6 +1070,44 @@ hk_status Ops<C>::wprog_run(hk_ctx* ctx, const hk_wprog* h, const uint32_t* inpu
     return HK_OK;
 }
 
+template <class C>
+hk_status Ops<C>::poseidon_path(hk_ctx* ctx, const void* consts, size_t n_consts, const hk_poseidon_desc* lh,
+                                const hk_poseidon_desc* nh, const void* leaf, const void* siblings, const uint32_t* index,
+                                size_t depth, size_t batch, size_t n_v, size_t col0, void* z_out) {
+    if (batch == 0) return HK_OK;
+    if (!consts || !lh || !nh || !leaf || !index || (depth && !siblings) || !is_device_ptr(z_out)) return HK_ERR_ARG;
+    if (batch >= (1u << 20) || depth > 32) return HK_ERR_ARG;
+    auto per_perm = [](const hk_poseidon_desc* d) -> size_t {          // witnesses of one permutation
+        size_t chain = d->alpha == 5 ? 3 : 5;
+        return (size_t)d->full_rounds * (d->t * chain + d->t) + (size_t)d->partial_rounds * (chain + d->t);
+    };
+    for (const hk_poseidon_desc* d : {lh, nh}) {
+        if (d->t < 2 || d->t > 4 || (d->alpha != 5 && d->alpha != 17) || (d->full_rounds & 1) ||
+            (size_t)d->consts_offset + (size_t)(d->full_rounds + d->partial_rounds) * d->t + (size_t)d->t * d->t > n_consts)
+            return HK_ERR_ARG;
+    }
+    if (lh->t != 4 || nh->t != 3) return HK_ERR_ARG;                   // rate 3 over the 4 leaf fields, rate 2 for two-to-one
+    size_t block = 2 * per_perm(lh) + depth * (3 + per_perm(nh));
+    if (col0 > n_v || block > n_v - col0) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    HK_TRY(L->reserve(al256(n_consts * sizeof(Fr)) + al256(batch * 4 * sizeof(Fr)) + al256(batch * depth * sizeof(Fr)) +
+                      al256(4 * batch) + 4096));
+    const void *cd, *ld, *sd = nullptr, *id;
+    HK_TRY(to_device(L, consts, n_consts * sizeof(Fr), &cd));
+    HK_TRY(to_device(L, leaf, batch * 4 * sizeof(Fr), &ld));
+    if (depth) HK_TRY(to_device(L, siblings, batch * depth * sizeof(Fr), &sd));
+    HK_TRY(to_device(L, index, 4 * batch, &id));
+    PoseidonDesc a{lh->t, lh->alpha, lh->full_rounds, lh->partial_rounds, lh->consts_offset};
+    PoseidonDesc b{nh->t, nh->alpha, nh->full_rounds, nh->partial_rounds, nh->consts_offset};
+    hipLaunchKernelGGL((k_poseidon_path<Fr>), dim3((u32)((batch + 63) / 64)), dim3(64), 0, L->stream, (const Fr*)cd, a, b,
+                       (const Fr*)ld, (const Fr*)sd, (const u32*)id, (u32)depth, (u32)batch, n_v, col0, (Fr*)z_out);
+    HK_HIP(hipGetLastError());
+    HK_HIP(hipStreamSynchronize(L->stream));
+    return HK_OK;
+}
+
 // ---- multi-pairings (pairing.cuh) ------------------------------------------------------------------------------
 template <class C>
 hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n_lhs, const void* const* rhs,

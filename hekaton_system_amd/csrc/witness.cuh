@@ -99,6 +99,76 @@ __global__ void k_scatter_full_batch(const u32* __restrict__ cols, const Fr* __r
     if (c < n_v) fr_store(&z_out[(size_t)b * n_v + c], fr_load(&vals[(size_t)b * k + j]));
 }
 
+// ---- Poseidon membership block (execution tree, subcircuit_circuit.rs:233-252) --------------------------------------
+// The host-side description of one Poseidon instance of the tree (poseidon_util.rs:53-62): width t = rate + 1 (3 or 4),
+// S-box exponent 5 or 17, rf full and rp partial rounds; consts = ark[(rf + rp)][t] then mds[t][t], Montgomery.
+struct PoseidonDesc { u32 t, alpha, rf, rp, off; };
+
+template <class Fr>
+__device__ __forceinline__ void poseidon_permute_trace(const Fr* __restrict__ consts, const PoseidonDesc& d, Fr (&s)[4],
+                                                       Fr*& w) {
+    const Fr* ark = consts + d.off;
+    const Fr* mds = ark + (size_t)(d.rf + d.rp) * d.t;
+    const u32 half = d.rf / 2;
+    for (u32 r = 0; r < d.rf + d.rp; r++) {
+        bool full = r < half || r >= half + d.rp;
+        Fr y[4];
+        for (u32 i = 0; i < d.t; i++) y[i] = Fr::add(s[i], fr_load(&ark[r * d.t + i]));
+        u32 nsb = full ? d.t : 1u;
+        for (u32 i = 0; i < nsb; i++) {
+            Fr u = y[i];
+            Fr x = Fr::mul(u, u);                       // u^2
+            fr_store(w++, x);
+            u32 squarings = d.alpha == 5 ? 1u : 3u;     // 5: u^2 u^4 u^5; 17: u^2 u^4 u^8 u^16 u^17
+            for (u32 k = 0; k < squarings; k++) { x = Fr::mul(x, x); fr_store(w++, x); }
+            x = Fr::mul(x, u);
+            fr_store(w++, x);
+            y[i] = x;
+        }
+        Fr n[4];
+        for (u32 i = 0; i < d.t; i++) {
+            Fr acc = Fr::mul(fr_load(&mds[i * d.t]), y[0]);
+            for (u32 j = 1; j < d.t; j++) acc = Fr::add(acc, Fr::mul(fr_load(&mds[i * d.t + j]), y[j]));
+            n[i] = acc;
+            fr_store(w++, acc);
+        }
+        for (u32 i = 0; i < d.t; i++) s[i] = n[i];
+    }
+}
+
+// One lane per subcircuit: the witnesses of its membership block, in the order sha_circuit.poseidon_path_trace lists
+// them - the leaf hash (sponge of rate 3 over the 4 leaf fields: two permutations), then per level the bit, the sibling,
+// the left input and the two-to-one hash - written straight into the assignment at column col0.
+// leaf: [batch][4], siblings: [batch][depth], index: [batch]; z: [batch][n_v].
+template <class Fr>
+__global__ void __launch_bounds__(64)
+k_poseidon_path(const Fr* __restrict__ consts, PoseidonDesc leaf_d, PoseidonDesc node_d, const Fr* __restrict__ leaf,
+                const Fr* __restrict__ siblings, const u32* __restrict__ index, u32 depth, u32 batch, size_t n_v,
+                size_t col0, Fr* __restrict__ z) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    Fr* w = z + (size_t)b * n_v + col0;
+    Fr s[4];
+    s[0] = Fr::zero();
+    for (u32 i = 0; i < 3; i++) s[1 + i] = fr_load(&leaf[(size_t)b * 4 + i]);
+    poseidon_permute_trace<Fr>(consts, leaf_d, s, w);
+    s[1] = Fr::add(s[1], fr_load(&leaf[(size_t)b * 4 + 3]));
+    poseidon_permute_trace<Fr>(consts, leaf_d, s, w);
+    Fr cur = s[1];
+    u32 idx = index[b];
+    for (u32 l = 0; l < depth; l++) {
+        Fr sib = fr_load(&siblings[(size_t)b * depth + l]);
+        bool bit = (idx >> l) & 1u;
+        Fr left = bit ? sib : cur, right = bit ? cur : sib;
+        fr_store(w++, bit ? Fr::one() : Fr::zero());
+        fr_store(w++, sib);
+        fr_store(w++, left);
+        s[0] = Fr::zero(); s[1] = left; s[2] = right; s[3] = Fr::zero();
+        poseidon_permute_trace<Fr>(consts, node_d, s, w);
+        cur = s[1];
+    }
+}
+
 #endif  // __HIPCC__
 
 }  // namespace hk

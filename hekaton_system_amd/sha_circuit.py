@@ -15,8 +15,13 @@ FUNCTION of a subcircuit and the shape of its two-stage R1CS:
               chain; root: digest field == root; padding: the chain over 64 zero bytes; every subcircuit: running
               products of (tr_chal - (val + entry_chal * addr)) over both subtraces (rom_transcript.rs:77-107), equal at
               the last subcircuit, and value-consistency of equal addresses in the address-ordered slice.
-    NOT reproduced: the Poseidon Merkle membership of the exec-tree leaf (subcircuit_circuit.rs:233-242) and the
-              address-sortedness comparison - both third-party gadget territory; the evals enter and leave as witnesses.
+              Also (round 3): the witnessed previous leaf (evals + last address-ordered entry of the previous
+              subcircuit), the address-step check of every consecutive pair of the address-ordered slice - next address
+              equal or larger by exactly one, equal addresses carry equal values (rom_portal_manager.rs:151-165) - and the
+              Poseidon Merkle membership of the subcircuit's OWN execution leaf (time eval, addr eval, last entry) under
+              the public root (subcircuit_circuit.rs:233-260; poseidon.py restates the hash).  The instance is the
+              reference's: (1, entry_chal, tr_chal, exec-tree root); the SHA tree's root hash is a witness, as in
+              tree_hash_circuit.rs:29-36,369-372 (`input_digest`: "TODO: Make this an actual public input").
 
 One program, two interpreters (`Tape`): BUILD records the R1CS rows (vectorised, 32 rows per word operation);
 EVAL runs the same program over a BATCH of subcircuits with numpy word arithmetic and emits the assignment directly
@@ -355,15 +360,40 @@ class Tape:
         return out
 
 
+def poseidon_path_trace(leaf_cfg, node_cfg, leaf, siblings, index):
+    """Every witness of the membership block of one subcircuit, in allocation order (= what `k_poseidon_path` writes):
+    the leaf hash's permutation traces, then per level (bit, sibling, left, the two-to-one hash's trace).  The last
+    value is the root the path leads to."""
+    out = []
+    cur = leaf_cfg.crh(leaf, out)
+    for lvl, sib in enumerate(siblings):
+        bit = (index >> lvl) & 1
+        left, right = (sib, cur) if bit else (cur, sib)
+        out += [bit, sib % leaf_cfg.p, left]
+        cur = node_cfg.crh([left, right], out)
+    return out
+
+
+def poseidon_path_root(leaf_cfg, node_cfg, leaf, siblings, index):
+    cur = leaf_cfg.crh(leaf)
+    for lvl, sib in enumerate(siblings):
+        cur = node_cfg.crh([sib, cur] if (index >> lvl) & 1 else [cur, sib])
+    return cur
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
     """One proving-key class of the re-implemented big-merkle circuit.  kind: "leaf" | "parent" | "root" | "padding";
     `first` marks subcircuit 0 (evals pinned to 1), `last` the final subcircuit (time eval == addr eval)."""
     N_INST = 4
 
-    def __init__(self, curve, kind, ns, n_portals, first=False, last=False):
+    def __init__(self, curve, kind, ns, n_portals, first=False, last=False, depth=3):
+        """depth = log2(number of subcircuits): the length of the execution tree's membership path."""
         assert kind in ("leaf", "parent", "root", "padding")
         self.curve, self.kind, self.ns, self.np_, self.first, self.last = curve, kind, ns, n_portals, first, last
+        self.depth = depth
+        from .poseidon import merkle_params
+        self.leaf_cfg, self.node_cfg = merkle_params(curve)
         self.r = CURVE_PARAMS[curve]["r"]
         self.fc = FrCodec(curve)
         self.n_time = self.n_addr = n_portals
@@ -415,12 +445,21 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
         a_final, a_vals = running(addr_e, inp["addr_eval0"] if ev else None, "addr")
         if self.last:
             t.big_row([(1, t_final), (r_mod - 1, a_final)], [(1, ONE)], [])
-        # value consistency of equal addresses in the address-ordered slice:
-        #   (addr' - addr) * inv = 1 - same ;  same * (addr' - addr) = 0 ;  same * (val' - val) = 0
-        for k in range(1, self.n_addr):
-            (a0, v0), (a1, v1) = addr_e[k - 1], addr_e[k]
+        # the previous leaf's last address-ordered entry (subcircuit_circuit.rs:167, 209-216): witnessed; padding - address
+        # 0 - in front of subcircuit 0 (:199-203; `is_padding` compares the address only, rom_transcript.rs:249-253)
+        prev = (t.alloc_full(inp["prev"][0] if ev else None), t.alloc_full(inp["prev"][1] if ev else None))
+        if self.first:
+            t.big_row([(1, prev[0])], [(1, ONE)], [])
+        # address-step check of every consecutive pair of [previous entry] + slice (rom_portal_manager.rs:151-165):
+        #   d = addr' - addr;  d * inv = 1 - same;  same * d = 0          (same = [d == 0], `is_eq`)
+        #   (1 - same) * (d - 1) = 0                                     (not the same address -> exactly one larger)
+        #   same * (val' - val) = 0                                      (`conditional_enforce_equal`)
+        chain = [prev] + addr_e
+        for k in range(1, len(chain)):
+            (a0, v0), (a1, v1) = chain[k - 1], chain[k]
             if ev:
-                d = [(int(x) - int(y)) % r_mod for x, y in zip(inp["addr"][k][0], inp["addr"][k - 1][0])]
+                prev_a = inp["prev"][0] if k == 1 else inp["addr"][k - 2][0]
+                d = [(int(x) - int(y)) % r_mod for x, y in zip(inp["addr"][k - 1][0], prev_a)]
                 inv = [pow(x, -1, r_mod) if x else 0 for x in d]
                 same = [0 if x else 1 for x in d]
             else:
@@ -428,7 +467,28 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
             inv_c, same_c = t.alloc_full(inv), t.alloc_full(same)
             t.big_row([(1, a1), (r_mod - 1, a0)], [(1, inv_c)], [(1, ONE), (r_mod - 1, same_c)])
             t.big_row([(1, same_c)], [(1, a1), (r_mod - 1, a0)], [])
+            t.big_row([(1, ONE), (r_mod - 1, same_c)], [(1, a1), (r_mod - 1, a0), (r_mod - 1, ONE)], [])
             t.big_row([(1, same_c)], [(1, v1), (r_mod - 1, v0)], [])
+        # ---- the subcircuit's own execution leaf is in the tree (subcircuit_circuit.rs:233-252)
+        self.pos_col0 = ni + t.n_wit
+        leaf_lcs = [[(1, t_final)], [(1, a_final)], [(1, addr_e[-1][0])], [(1, addr_e[-1][1])]]
+        if ev:
+            leaf_vals = [[t_vals[b], a_vals[b], int(inp["addr"][-1][0][b]) % r_mod, int(inp["addr"][-1][1][b]) % r_mod]
+                         for b in range(B)]
+            traces = [poseidon_path_trace(self.leaf_cfg, self.node_cfg, leaf_vals[b], inp["path_sib"][b], inp["path_idx"][b])
+                      for b in range(B)]
+            cols_vals = list(zip(*traces))                       # per witness of the block: its value per batch element
+            self._pos_iter = iter(cols_vals)
+        nxt = (lambda: t.alloc_full(list(next(self._pos_iter)))) if ev else (lambda: t.alloc_full(None))
+        cur = self._poseidon_crh(t, self.leaf_cfg, leaf_lcs, nxt)
+        for _lvl in range(self.depth):
+            bit, sib, left = nxt(), nxt(), nxt()
+            t.big_row([(1, bit)], [(1, ONE), (r_mod - 1, bit)], [])                               # boolean
+            t.big_row([(1, bit)], [(1, sib), (r_mod - 1, cur)], [(1, left), (r_mod - 1, cur)])    # left = bit ? sib : cur
+            right = [(1, sib), (1, cur), (r_mod - 1, left)]                                        # the other one
+            cur = self._poseidon_crh(t, self.node_cfg, [[(1, left)], right], nxt)
+        t.big_row([(1, cur), (r_mod - 1, ROOT)], [(1, ONE)], [])                                   # the public root
+        self.pos_cols = ni + t.n_wit - self.pos_col0
         # ---- the hash chain
         if self.kind in ("leaf", "padding"):
             # 64 witnessed bytes as 16 big-endian words (bits boolean)
@@ -450,8 +510,57 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
             out_col = time_e[-1][1]                        # the `set` is the subcircuit's last time-ordered operation
             t.big_row(terms, [(1, ONE)], [(1, out_col)])
         elif self.kind == "root":
-            t.big_row(terms, [(1, ONE)], [(1, ROOT)])
+            # the SHA tree's root hash: a witness in the reference too (tree_hash_circuit.rs:29-36 `input_digest`)
+            sha_root = t.alloc_full(inp["sha_root"] if ev else None)
+            self.sha_root_col = sha_root
+            t.big_row(terms, [(1, ONE)], [(1, sha_root)])
         return digest
+
+    def _poseidon_crh(self, t, cfg, inputs, nxt):
+        """`poseidon::constraints::CRHGadget::evaluate` with an own layout: inputs = linear combinations [(coef, col)];
+        per round the S-box chain of every S-boxed element and the new state are witnesses (`nxt()` allocates the next
+        one, in the order poseidon.PoseidonConfig.permute traces them); returns the digest's column."""
+        p, tt = cfg.p, cfg.t
+        state = [[] for _ in range(tt)]                      # linear combinations; [] = 0
+        k = 0
+        while True:
+            blk = inputs[k:k + cfg.rate]
+            for i, lc in enumerate(blk):
+                state[1 + i] = state[1 + i] + lc
+            k += len(blk)
+            if k >= len(inputs):
+                break
+            state = self._poseidon_permute(t, cfg, state, nxt)
+        state = self._poseidon_permute(t, cfg, state, nxt)
+        return state[1][0][1]
+
+    def _poseidon_permute(self, t, cfg, state, nxt):
+        half = cfg.rf // 2
+        for r in range(cfg.rf + cfg.rp):
+            full = r < half or r >= half + cfg.rp
+            y = [state[i] + [(cfg.ark[r][i], ONE)] for i in range(cfg.t)]
+            for i in range(cfg.t if full else 1):
+                u = y[i]
+                prev_col = None
+                n_chain = 3 if cfg.alpha == 5 else 5
+                for step in range(n_chain):
+                    c = nxt()
+                    if step == 0:
+                        t.big_row(u, u, [(1, c)])                                  # u^2
+                    elif step < n_chain - 1:
+                        t.big_row([(1, prev_col)], [(1, prev_col)], [(1, c)])      # squarings
+                    else:
+                        t.big_row([(1, prev_col)], u, [(1, c)])                    # x^(alpha-1) * u
+                    prev_col = c
+                y[i] = [(1, prev_col)]
+            new = []
+            for i in range(cfg.t):
+                c = nxt()
+                lc = [(cfg.mds[i][j] * coef % cfg.p, col) for j in range(cfg.t) for coef, col in y[j]]
+                t.big_row(lc, [(1, ONE)], [(1, c)])
+                new.append([(1, c)])
+            state = new
+        return state
 
     @staticmethod
     def _enforce_word_eq(t, w, z):
@@ -607,6 +716,10 @@ class ShaMerkleSubcircuit(MultiStageConstraintSynthesizer):
             inp[key] = [([i[key][k][0] for i in inputs], [i[key][k][1] for i in inputs]) for k in range(n)]
         inp["time_eval0"] = [i["time_eval0"] for i in inputs]
         inp["addr_eval0"] = [i["addr_eval0"] for i in inputs]
+        inp["prev"] = ([i["prev"][0] for i in inputs], [i["prev"][1] for i in inputs])
+        inp["path_sib"] = [i["path"][0] for i in inputs]
+        inp["path_idx"] = [i["path"][1] for i in inputs]
+        inp["sha_root"] = [i.get("sha_root", 0) for i in inputs]
         if self.kind in ("leaf", "padding"):
             leaves = np.frombuffer(b"".join(i["leaf"] for i in inputs), np.uint8).reshape(B, 64)
             inp["leaf_words"] = leaves.reshape(B, 16, 4).astype(np.uint32) @ np.array([1 << 24, 1 << 16, 1 << 8, 1], np.uint32)
@@ -693,18 +806,43 @@ def example_witness(circ, seed=0, entry_chal=None, tr_chal=None):
     if circ.kind in ("leaf", "parent"):
         time[-1] = (rnd.randrange(1 << 20), out)
     w["time"] = time
-    # an address-ordered slice: sorted by address, duplicates carry equal values
-    addr = sorted((rnd.randrange(1 << 20), rnd.randrange(r)) for _ in range(circ.n_addr))
-    if circ.n_addr > 1:
-        addr[1] = addr[0]
-    w["addr"] = addr
+    # an address-ordered slice that passes the step check: consecutive addresses equal or one apart, equal addresses carry
+    # equal values; the previous subcircuit's last entry in front of it (padding (0, 0) before subcircuit 0)
+    a0 = 0 if circ.first else rnd.randrange(1 << 20)
+    prev = (a0, 0 if circ.first else rnd.randrange(r))
+    addr, cur = [], prev
+    for k in range(circ.n_addr):
+        if k == 1 or rnd.random() < 0.4:
+            nxt = cur                                            # same address, same value
+        else:
+            nxt = (cur[0] + 1, rnd.randrange(r))
+        addr.append(nxt)
+        cur = nxt
+    w["addr"], w["prev"] = addr, prev
     w["time_eval0"] = 1 if circ.first else rnd.randrange(1, r)
     w["addr_eval0"] = 1 if circ.first else rnd.randrange(1, r)
-    w["root"] = out if circ.kind == "root" else rnd.randrange(r)
+    if circ.kind == "root":
+        w["sha_root"] = out
     if circ.last:
-        # the permutation check needs equal final evals: make the two traces the same multiset and the starts equal
-        w["addr"] = sorted(time)
+        # the permutation check needs equal final evals: the address-ordered slice is the time-ordered one sorted - with
+        # addresses that pass the step check - and the starts are equal
+        time = [(prev[0] + 1 + k, v) for k, (_a, v) in enumerate(time)]      # strictly increasing: no value constraints
+        w["time"] = time
+        w["addr"] = list(time)
         w["addr_eval0"] = w["time_eval0"]
+    # the execution leaf this subcircuit produces and a random membership path for it; the root follows
+    ech, tr = w["entry_chal"], w["tr_chal"]
+    step = lambda c, e: c * ((tr - (e[1] + ech * e[0])) % r) % r
+    te, ae = w["time_eval0"], w["addr_eval0"]
+    for e in w["time"]:
+        te = step(te, e)
+    for e in w["addr"]:
+        ae = step(ae, e)
+    leaf = [te, ae, w["addr"][-1][0] % r, w["addr"][-1][1] % r]
+    sib = [rnd.randrange(r) for _ in range(circ.depth)]
+    idx = rnd.randrange(1 << circ.depth)
+    w["path"] = (sib, idx)
+    w["root"] = poseidon_path_root(circ.leaf_cfg, circ.node_cfg, leaf, sib, idx)
     return w
 
 
@@ -748,7 +886,9 @@ class ShaMerkleJob:
             l, rr = self.children[jj]
             self.digest[jj] = iterated_sha256(self.digest[l][:INNER_HASH_SIZE] + self.digest[rr][:INNER_HASH_SIZE], ns)
         self.digest[n - 1] = iterated_sha256(bytes(64), ns)
-        self.root = node_hash_field(self.digest[n - 2])
+        self.sha_root = node_hash_field(self.digest[n - 2])            # the data tree's root hash (a witness of the root class)
+        self.root = None                                               # the EXECUTION tree's root: known after `set_challenges`
+        self.depth = n.bit_length() - 1
         val = lambda jj: node_hash_field(self.digest[jj])
         # time-ordered trace
         self.time = []
@@ -792,6 +932,13 @@ class ShaMerkleJob:
             self.time_eval0.append(t)
             self.addr_eval0.append(a)
         assert self.time_eval0[-1] == self.addr_eval0[-1]          # same multiset: the permutation check will hold
+        # the execution tree (coordinator.rs:125-174): leaf i = (evals after subcircuit i, last entry of its address-ordered
+        # slice); every subcircuit gets the membership path of its own leaf (coordinator.rs:446-452)
+        from .poseidon import ExecTree
+        leaves = [[self.time_eval0[i + 1], self.addr_eval0[i + 1], self.addr[i][-1][0] % r, self.addr[i][-1][1] % r]
+                  for i in range(n)]
+        self.tree = ExecTree(self.curve, leaves)
+        self.root = self.tree.root
 
     def class_of(self, idx):
         """(kind, first, last) - the proving-key class a subcircuit needs (5 classes, tree_hash_circuit.rs:192-216)."""
@@ -799,11 +946,14 @@ class ShaMerkleJob:
 
     def make_class(self, idx):
         kind, first, last = self.class_of(idx)
-        return ShaMerkleSubcircuit(self.curve, kind, self.ns, self.np_, first=first, last=last)
+        return ShaMerkleSubcircuit(self.curve, kind, self.ns, self.np_, first=first, last=last, depth=self.depth)
 
     def inputs(self, idx):
+        """What the subcircuit's Stage1Request carries (coordinator.rs:569-604): challenges, the previous leaf (evals and
+        last entry; padding before subcircuit 0), the membership path of its own leaf, the root."""
         w = dict(entry_chal=self.entry_chal, tr_chal=self.tr_chal, root=self.root, time=self.time[idx], addr=self.addr[idx],
-                 time_eval0=self.time_eval0[idx], addr_eval0=self.addr_eval0[idx])
+                 time_eval0=self.time_eval0[idx], addr_eval0=self.addr_eval0[idx],
+                 prev=(self.addr[idx - 1][-1] if idx else (0, 0)), path=self.tree.path(idx), sha_root=self.sha_root)
         if self.kind[idx] == "leaf":
             w["leaf"] = self.leaves[idx]
         elif self.kind[idx] == "padding":
@@ -893,8 +1043,31 @@ def full_values(circ, inputs):
                 e = (v + ech * a) % r
                 cur = cur * ((tr - e) % r) % r
                 vals += [e, cur]; c_local += [col, col + 1]; col += 2
-        for k in range(1, circ.n_addr):
-            d = (w["addr"][k][0] - w["addr"][k - 1][0]) % r
+        vals += [w["prev"][0], w["prev"][1]]; c_local += [col, col + 1]; col += 2
+        chain = [w["prev"]] + list(w["addr"])
+        for k in range(1, len(chain)):
+            d = (chain[k][0] - chain[k - 1][0]) % r
             vals += [pow(d, -1, r) if d else 0, 0 if d else 1]; c_local += [col, col + 1]; col += 2
+        assert col == circ.pos_col0                       # the membership block follows: k_poseidon_path fills it
+        if circ.kind == "root":
+            vals.append(w["sha_root"]); c_local.append(circ.sha_root_col)
         rows.append(circ.fc.enc(vals))
     return np.array(cols + c_local, np.uint32), np.stack(rows)
+
+
+def poseidon_inputs(circ, inputs):
+    """Per subcircuit, what `hk_poseidon_path` needs to fill the membership block on the device: the execution leaf
+    (4 field values: the final evals and the last address-ordered entry), the path's siblings and the leaf index."""
+    r = circ.r
+    leaves, sibs, idx = [], [], []
+    for w in inputs:
+        ech, tr = w["entry_chal"], w["tr_chal"]
+        te, ae = w["time_eval0"], w["addr_eval0"]
+        for a, v in w["time"]:
+            te = te * ((tr - (v + ech * a)) % r) % r
+        for a, v in w["addr"]:
+            ae = ae * ((tr - (v + ech * a)) % r) % r
+        leaves.append(circ.fc.enc([te, ae, w["addr"][-1][0] % r, w["addr"][-1][1] % r]))
+        sibs.append(circ.fc.enc(list(w["path"][0])))
+        idx.append(w["path"][1])
+    return np.stack(leaves), np.stack(sibs), np.array(idx, np.uint32)

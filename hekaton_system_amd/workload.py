@@ -397,7 +397,7 @@ def make_sha_config(curve, name, class_rep, n_total=None):
     n = n_total or n
     rep = 1 if class_rep is None else class_rep
     kind = "leaf" if rep < n // 2 else ("padding" if rep == n - 1 else ("root" if rep == n - 2 else "parent"))
-    return ShaMerkleSubcircuit(curve, kind, ns, n_portals, first=(rep == 0), last=(rep == n - 1))
+    return ShaMerkleSubcircuit(curve, kind, ns, n_portals, first=(rep == 0), last=(rep == n - 1), depth=n.bit_length() - 1)
 
 
 def make_config(curve, name, class_rep=None, n_total=None):

@@ -255,6 +255,20 @@ void      hk_wprog_free(hk_wprog* w);
 hk_status hk_wprog_run(hk_ctx* ctx, const hk_wprog* w, const uint32_t* inputs, size_t batch, const uint32_t* full_cols,
                        const void* full_vals_mont, size_t n_full, void* z_out);
 
+/* The Poseidon membership block of a subcircuit's assignment (the witness side of `verify_membership`,
+ * distributed-prover/src/subcircuit_circuit.rs:233-252, with the hashes of poseidon_util.rs:26-107): for `batch`
+ * subcircuits at once, the S-box chains and round states of the leaf hash (rate 3 over the 4 leaf fields) and of the
+ * `depth` two-to-one hashes along the path, plus per level (bit, sibling, left input), written to columns
+ * [col0, col0 + block) of each subcircuit's assignment in HBM - the order of hekaton_system_amd/sha_circuit.py
+ * `poseidon_path_trace`.  hk_poseidon_desc: width t = rate + 1 (<= 4), S-box exponent (5 or 17), full / partial rounds,
+ * offset (in Fr elements) of its constants inside `consts_mont` = ark[(rf + rp)][t] then mds[t][t].
+ *   consts_mont [h|d]; leaf_mont [h|d] batch x 4 Fr; siblings_mont [h|d] batch x depth Fr (bottom-up: the leaf's sibling
+ *   first); leaf_index [h|d] batch u32; z_out [d] batch x n_v Fr.  HK_ERR_ARG for a block that would not fit n_v. */
+typedef struct { uint32_t t, alpha, full_rounds, partial_rounds, consts_offset; } hk_poseidon_desc;
+hk_status hk_poseidon_path(hk_ctx* ctx, const void* consts_mont, size_t n_consts, const hk_poseidon_desc* leaf_hash,
+                           const hk_poseidon_desc* node_hash, const void* leaf_mont, const void* siblings_mont,
+                           const uint32_t* leaf_index, size_t depth, size_t batch, size_t n_v, size_t col0, void* z_out);
+
 /* ---- proving-key residency -------------------------------------------------------------- */
 hk_status hk_pk_upload(hk_ctx* ctx, const hk_pk_desc* desc, hk_pk** out);
 void      hk_pk_free(hk_pk* pk);

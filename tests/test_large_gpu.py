@@ -263,19 +263,24 @@ def test_assignment_materialised_on_the_device_equals_the_host_bytes(ctx_bn254):
 
 @pytest.mark.parametrize("kind", ["leaf", "parent"])
 def test_witness_generated_on_the_device_equals_the_host_trace(kind, ctx_bn254):
-    """hk_wprog_upload / hk_wprog_run (csrc/witness.cuh): the class's word program interpreted on the GPU from the
-    subcircuits' inputs gives, bit for bit, the assignments the numpy trace emits (themselves checked against hashlib
-    and the R1CS on the CPU); then a proof from the device-generated assignment verifies."""
+    """hk_wprog_upload / hk_wprog_run + hk_poseidon_path (csrc/witness.cuh): the class's word program interpreted on the
+    GPU from the subcircuits' inputs, and the Poseidon membership block computed on the GPU from the execution leaf and
+    its path, give bit for bit the assignments the host trace emits (themselves checked against hashlib, poseidon.py and
+    the R1CS on the CPU); then a proof from the device-generated assignment verifies."""
     from hekaton_system_amd.cp_groth16 import trapdoor_verify
-    from hekaton_system_amd.sha_circuit import (ShaMerkleSubcircuit, example_witness, full_values, program_inputs)
+    from hekaton_system_amd.poseidon import device_params
+    from hekaton_system_amd.sha_circuit import (ShaMerkleSubcircuit, example_witness, full_values, poseidon_inputs,
+                                                program_inputs)
     cname = "bn254"
     fc = FrCodec(cname)
-    circ = ShaMerkleSubcircuit(cname, kind, ns=2, n_portals=4)
+    circ = ShaMerkleSubcircuit(cname, kind, ns=2, n_portals=4, depth=5)
     ws = [example_witness(circ, seed=s, entry_chal=31, tr_chal=41) for s in range(5)]
     ops, refs, vmap = circ.tape.word_program(circ.n_v)
     wp = ctx_bn254.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
     cols, vals = full_values(circ, ws)
     zdev = wp.run(program_inputs(circ, ws), cols, vals)
+    leaves, sibs, idx = poseidon_inputs(circ, ws)
+    ctx_bn254.poseidon_path(device_params(cname, fc), leaves, sibs, idx, circ.n_v, circ.pos_col0, zdev)
     got = zdev.to_host().reshape(len(ws), -1)
     want = circ.assignment_bytes(ws)
     assert np.array_equal(got, want)

@@ -78,7 +78,10 @@ def test_whole_job_witness_generation():
     h = [hashlib.sha256(l).digest() for l in leaves]
     l1 = [hashlib.sha256(h[0][:27] + h[1][:27]).digest(), hashlib.sha256(h[2][:27] + h[3][:27]).digest()]
     root = hashlib.sha256(l1[0][:27] + l1[1][:27]).digest()
-    assert job.digest[6] == root and job.root == int.from_bytes(root[:27], "little")
+    assert job.digest[6] == root and job.sha_root == int.from_bytes(root[:27], "little")
+    # the public root is the EXECUTION tree's (Poseidon over the leaves (evals after subcircuit i, last addr-ordered entry)):
+    # every subcircuit's path leads to it
+    assert all(job.tree.verify(job.tree.leaves[i], *job.tree.path(i)) for i in range(8)) and job.root == job.tree.root
     assert [job.class_of(i)[0] for i in range(8)] == ["leaf"] * 4 + ["parent", "parent", "root", "padding"]
     classes = {}
     for idx in range(8):
@@ -92,14 +95,45 @@ def test_whole_job_witness_generation():
         for i, z, d in zip(members, zs, digests):
             assert d == job.digest[i]
             assert _check_r1cs(circ, z) == [], (kind, i)
-    # a job with one leaf changed has a different root, and the old root is then unprovable in the root subcircuit
+    # a job with one leaf changed has a different data root, and the old one is then unprovable in the root subcircuit
     job2 = ShaMerkleJob("bn254", 8, 1, 4, [leaves[0], leaves[1], leaves[2], bytes(64)], entry_chal=0xabc, tr_chal=0xdef123)
-    assert job2.root != job.root
+    assert job2.sha_root != job.sha_root and job2.root != job.root
     circ = job2.make_class(6)
     circ.csr(circ.fc)
     w = job2.inputs(6)
-    w["root"] = job.root
+    w["sha_root"] = job.sha_root
     assert _check_r1cs(circ, circ.assignment_ints(w)[0]) != []
+    # the membership check: another public root, a sibling of the path changed, the index flipped - each unprovable
+    circ, members = classes[("leaf", False, False)]
+    for tamper in ("root", "sibling", "index"):
+        w = dict(job.inputs(members[0]))
+        sib, idx = w["path"]
+        if tamper == "root":
+            w["root"] = (w["root"] + 1) % circ.r
+        elif tamper == "sibling":
+            w["path"] = ([sib[0], (sib[1] + 1) % circ.r] + sib[2:], idx)
+        else:
+            w["path"] = (sib, idx ^ 2)
+        assert _check_r1cs(circ, circ.assignment_ints(w)[0]) != [], tamper
+    # the address-step check (rom_portal_manager.rs:151-165): a slice whose address jumps by two, or whose equal addresses
+    # carry different values, is unprovable even with evals and leaf recomputed consistently
+    from hekaton_system_amd.sha_circuit import poseidon_path_root
+    def reroot(w):
+        ech, tr, r = w["entry_chal"], w["tr_chal"], circ.r
+        te, ae = w["time_eval0"], w["addr_eval0"]
+        for a, v in w["time"]:
+            te = te * ((tr - (v + ech * a)) % r) % r
+        for a, v in w["addr"]:
+            ae = ae * ((tr - (v + ech * a)) % r) % r
+        w["root"] = poseidon_path_root(circ.leaf_cfg, circ.node_cfg, [te, ae, w["addr"][-1][0] % r, w["addr"][-1][1] % r], *w["path"])
+        return w
+    w = dict(job.inputs(members[0]))
+    assert _check_r1cs(circ, circ.assignment_ints(reroot(dict(w)))[0]) == []          # the helper itself is sound
+    jump = dict(w); jump["addr"] = list(w["addr"]); jump["addr"][-1] = (w["addr"][-1][0] + 2, w["addr"][-1][1])
+    assert _check_r1cs(circ, circ.assignment_ints(reroot(jump))[0]) != []
+    k = next(k for k in range(1, 4) if w["addr"][k][0] == w["addr"][k - 1][0])
+    diff = dict(w); diff["addr"] = list(w["addr"]); diff["addr"][k] = (w["addr"][k][0], w["addr"][k][1] + 1)
+    assert _check_r1cs(circ, circ.assignment_ints(reroot(diff))[0]) != []
 
 
 @pytest.mark.parametrize("kind", ["leaf", "parent", "root", "padding"])
@@ -116,10 +150,18 @@ def test_word_program_reproduces_the_trace(kind):
     got = ((vals[vmap[mask] >> 5] >> (vmap[mask] & 31)[:, None]) & 1).T.astype(np.uint8)
     assert np.array_equal(got, bits_ref[:, mask])
     cols, fv = full_values(circ, ws)
-    assert sorted(cols.tolist()) == sorted([1, 2, 3] + list(full_ref.keys()))
-    assert set(np.nonzero(~mask)[0].tolist()) == set(cols.tolist()) | {0}
+    # full-width columns = the host-computed values + the membership block (filled by k_poseidon_path on the device, by
+    # poseidon_path_trace here)
+    block = list(range(circ.pos_col0, circ.pos_col0 + circ.pos_cols))
+    assert sorted(cols.tolist() + block) == sorted([1, 2, 3] + list(full_ref.keys()))
+    assert set(np.nonzero(~mask)[0].tolist()) == set(cols.tolist()) | set(block) | {0}
     zs = circ.assignment_ints(ws)
     fc = circ.fc
+    from hekaton_system_amd.sha_circuit import poseidon_inputs, poseidon_path_trace
+    leaves, sibs, idx = poseidon_inputs(circ, ws)
     for b in range(3):
         dec = fc.dec(fv[b])
         assert all(dec[k] == zs[b][c] for k, c in enumerate(cols.tolist()))
+        tr = poseidon_path_trace(circ.leaf_cfg, circ.node_cfg, fc.dec(leaves[b]), fc.dec(sibs[b]), int(idx[b]))
+        assert len(tr) == circ.pos_cols and tr == zs[b][circ.pos_col0:circ.pos_col0 + circ.pos_cols]
+        assert tr[-2] == ws[b]["root"]                   # state[1] of the last permutation = the root
