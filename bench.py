@@ -437,7 +437,7 @@ def end_to_end(job, use_dist, two_rounds_s):
     super commitment, `agg_subcircuit_proofs` (IPP commitments, twisted vectors, 4 x 4 cross terms, TIPA prove) and the
     verifier's TIPA check.  Its pairing-product assertion (aggregation.rs:265-269) holds only if EVERY timed proof
     satisfies the Groth16 verifier equation under its class's verifying key, so this is also the check of all timed
-    proofs.  Key generation (TIPA SRS, AggProvingKey::new) is reported separately and not counted."""
+    proofs.  Key generation (TIPA SRS, AggProvingKey::new) is inside total_s, as in the reference's `work`."""
     import numpy as np
     from hekaton_system_amd import aggregation as agg, tipa
     from hekaton_system_amd.cp_groth16 import Proof
@@ -488,12 +488,18 @@ def end_to_end(job, use_dist, two_rounds_s):
         res = {"super_commitment_s": tb - ta, "aggregate_s": tc - tb, "verify_s": td - tc}
     for rb in srs.resident.values():
         rb.free()
-    res.update({"subcircuits": n, "two_rounds_s": two_rounds_s, "total_s": two_rounds_s + res["super_commitment_s"] + res["aggregate_s"],
+    setup_s = (t1 - t0) + (t2 - t1)
+    proving_s = two_rounds_s + res["super_commitment_s"] + res["aggregate_s"]
+    res.update({"subcircuits": n, "two_rounds_s": two_rounds_s,
+                # the reference's `work` builds the aggregation key inside the job and times it (mpi-snark/src/coordinator.rs:
+                # 27-40,80-97: generate_agg_key -> TIPA::setup(N) + AggProvingKey::new): it is part of total_s
+                "tipa_setup_s": t1 - t0, "agg_key_s": t2 - t1,
+                "total_s": setup_s + proving_s, "total_without_agg_key_setup_s": proving_s,
                 "all_timed_proofs_pass_the_pairing_product_equation": True, "tipa_proof_verified": True,
-                "not_counted": {"tipa_setup_s": t1 - t0, "agg_key_s": t2 - t1},
-                "note": "two_rounds_s = one timed step (commit round, gather, prove round, gather); aggregation of that step's proofs "
-                        "measured once after the timed region (second of two runs); total_s = proving wall-clock of the job up to the "
-                        "aggregate proof"})
+                "note": "two_rounds_s = one timed step (commit round, gather, prove round, gather); aggregator key setup and "
+                        "aggregation of that step's proofs measured once after the timed region (aggregation: second of two runs); "
+                        "total_s = job wall-clock up to the aggregate proof as the reference's `work` counts it (setup included); "
+                        "total_without_agg_key_setup_s = the figure earlier rounds reported as total_s"})
     return res
 
 

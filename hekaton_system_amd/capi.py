@@ -190,6 +190,19 @@ class DeviceBuffer:
             load().hk_dev_free(self.ctx.handle, self.ptr)
             self.ptr = None
 
+    def view(self, offset, nbytes):
+        """A window of this allocation, usable wherever a DeviceBuffer is (it owns nothing: free() is a no-op)."""
+        assert 0 <= offset and offset + nbytes <= self.nbytes
+        return DeviceView(self.ctx, self.ptr + int(offset), int(nbytes))
+
+
+class DeviceView(DeviceBuffer):
+    def __init__(self, ctx, ptr_, nbytes):            # noqa: super().__init__ would allocate
+        self.ctx, self.ptr, self.nbytes = ctx, ptr_, nbytes
+
+    def free(self):
+        pass
+
 
 class Context:
     """hk_ctx wrapper: one per (process, device)."""
@@ -260,14 +273,15 @@ class Context:
         check(fn(self.handle, base.ctypes.data, ptr(scalars), n, int(montgomery), ptr(res)), fn.__name__)
         return res
 
-    def scalar_pairing(self, group, points, scalars, n=None):
-        """`scalar_pairing` (distributed-prover/src/pairing_ops.rs:32-39): out[i] = scalars[i] * points[i]."""
+    def scalar_pairing(self, group, points, scalars, n=None, out=None):
+        """`scalar_pairing` (distributed-prover/src/pairing_ops.rs:32-39): out[i] = scalars[i] * points[i].  `out` may be a
+        DeviceBuffer (the result stays in HBM)."""
         pb = self.g1_bytes if group == 1 else self.g2_bytes
         n = n if n is not None else len(scalars) // self.fr_bytes
         fn = self.lib.hk_scalar_pairing_g1 if group == 1 else self.lib.hk_scalar_pairing_g2
-        out = np.zeros(n * pb, dtype=np.uint8)
-        check(fn(self.handle, ptr(points), ptr(scalars), n, out.ctypes.data), fn.__name__)
-        return out
+        res = out if out is not None else np.zeros(n * pb, dtype=np.uint8)
+        check(fn(self.handle, ptr(points), ptr(scalars), n, ptr(res)), fn.__name__)
+        return res
 
     def gt_pow(self, gts, scalars):
         """hk_gt_pow: element-wise powers in GT.  gts: (n, gt_bytes) uint8; scalars: n Fr Montgomery bytes."""
@@ -311,7 +325,7 @@ class Context:
         check(fn(self.handle, vp_, coeffs.ctypes.data, len(keep), n, out.ctypes.data), fn.__name__)
         return out
 
-    def points_fold_g2(self, lo, hi, c, n=None):
+    def points_fold_g2(self, lo, hi, c, n=None, out=None):
         """out[i] = lo[i] + c * hi[i] in G2 (the fold of a TIPA round) through hk_points_fold_g2: the scalar c (an int mod r)
         is split along the endomorphism psi into four ~64-bit parts (endo.Psi4), so the element-wise double-and-add chain is
         ~66 steps instead of 254."""
@@ -323,12 +337,12 @@ class Context:
         coeffs = np.ascontiguousarray(FrCodec(self.curve).enc([abs(v) for v in k]), dtype=np.uint8)
         lo_, hi_ = (x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8) for x in (lo, hi))
         ptr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data
-        out = np.zeros(n * self.g2_bytes, dtype=np.uint8)
-        check(self.lib.hk_points_fold_g2(self.handle, ptr(lo_), ptr(hi_), coeffs.ctypes.data, neg, n, out.ctypes.data),
-              "hk_points_fold_g2")
-        return out
+        res = out if out is not None else np.zeros(n * self.g2_bytes, dtype=np.uint8)          # a DeviceBuffer stays in HBM
+        check(self.lib.hk_points_fold_g2(self.handle, ptr(lo_), ptr(hi_), coeffs.ctypes.data, neg, n,
+                                         res.ptr if isinstance(res, DeviceBuffer) else res.ctypes.data), "hk_points_fold_g2")
+        return res
 
-    def points_fold_g1(self, lo, hi, c, n=None):
+    def points_fold_g1(self, lo, hi, c, n=None, out=None):
         """out[i] = lo[i] + c * hi[i] in G1 through hk_points_fold_g1: c split along the GLV endomorphism into two ~128-bit
         parts (endo.Phi2)."""
         from .cp_groth16 import FrCodec
@@ -339,10 +353,10 @@ class Context:
         coeffs = np.ascontiguousarray(FrCodec(self.curve).enc([abs(v) for v in k]), dtype=np.uint8)
         lo_, hi_ = (x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8) for x in (lo, hi))
         ptr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data
-        out = np.zeros(n * self.g1_bytes, dtype=np.uint8)
-        check(self.lib.hk_points_fold_g1(self.handle, ptr(lo_), ptr(hi_), coeffs.ctypes.data, neg, n, out.ctypes.data),
-              "hk_points_fold_g1")
-        return out
+        res = out if out is not None else np.zeros(n * self.g1_bytes, dtype=np.uint8)          # a DeviceBuffer stays in HBM
+        check(self.lib.hk_points_fold_g1(self.handle, ptr(lo_), ptr(hi_), coeffs.ctypes.data, neg, n,
+                                         res.ptr if isinstance(res, DeviceBuffer) else res.ctypes.data), "hk_points_fold_g1")
+        return res
 
     def assignment_from_bits(self, bits, full_cols, full_vals, out=None):
         """hk_assignment_from_bits: the Montgomery assignment of a bit-valued witness, materialised in HBM.  bits: uint8

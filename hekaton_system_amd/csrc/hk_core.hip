@@ -37,11 +37,45 @@ static uint64_t scratch_limit_bytes() {
 }
 static std::atomic<size_t> g_deepest_frame{0};             // over every curve a context was created for in this process
 
-hk_status scratch_budget_check(const CurveOps* ops, const hipDeviceProp_t& prop) {
+// Ring pre-sizing.  A queue's ring is re-allocated every time a kernel with a deeper frame than it has seen arrives; rings
+// that grow one after another through several sizes fragment the agent's scratch range, and a request can then fail with
+// most of the budget free.  Every stream a lane creates therefore first runs one wave of a kernel whose frame is the
+// deepest of the process (rounded up to 256 B), in stream-creation = queue order: each ring is allocated once, at its
+// final size.  k_scratch_presize<W> owns W * 4 bytes of private memory (runtime-indexed, so it cannot live in registers).
+template <int WORDS>
+__global__ void __launch_bounds__(64) k_scratch_presize(unsigned* sink, unsigned seed) {
+    unsigned buf[WORDS];
+    unsigned x = seed + threadIdx.x;
+    for (int i = 0; i < WORDS; i += 16) buf[i] = x + i;
+    unsigned j = (x * 2654435761u) % (unsigned)WORDS;
+    buf[j & ~15u] += x;
+    if (sink && buf[(j * 7u) % (unsigned)WORDS & ~15u] == 0x9e3779b9u) *sink = x;     // never true in practice; keeps buf alive
+}
+typedef void (*presize_fn)(unsigned*, unsigned);
+template <int... I> struct PresizeTable { static const presize_fn fn[sizeof...(I)]; };
+template <int... I> const presize_fn PresizeTable<I...>::fn[sizeof...(I)] = {k_scratch_presize<64 * (I + 1)>...};
+typedef PresizeTable<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+                     30, 31> Presize;                        // frames of 256 B ... 8 KiB
+static presize_fn presize_kernel_for(size_t frame, size_t* actual) {
+    size_t idx = frame ? (frame + 255) / 256 - 1 : 0;
+    if (idx > 31) idx = 31;
+    for (; idx < 32; idx++) {                               // the compiler may add a few bytes: take the first that is deep enough
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void*)Presize::fn[idx]) != hipSuccess) { (void)hipGetLastError(); break; }
+        if ((size_t)fa.localSizeBytes >= frame || idx == 31) { *actual = (size_t)fa.localSizeBytes; return Presize::fn[idx]; }
+    }
+    *actual = frame;
+    return nullptr;
+}
+
+hk_status scratch_budget_check(const CurveOps* ops, const hipDeviceProp_t& prop, void** presize_out) {
     size_t frame = ops->max_private_bytes ? ops->max_private_bytes() : 0;
     size_t prev = g_deepest_frame.load();
     while (frame > prev && !g_deepest_frame.compare_exchange_weak(prev, frame)) {}
     frame = g_deepest_frame.load();
+    size_t presized = frame;
+    *presize_out = (void*)presize_kernel_for(frame, &presized);
+    if (presized > frame) frame = presized;                 // the ring every queue will actually hold
     const char* q = getenv("GPU_MAX_HW_QUEUES");
     uint64_t queues = q && atoi(q) > 0 ? (uint64_t)atoi(q) : 4;          // the HIP runtime's default
     uint64_t slots = (uint64_t)prop.multiProcessorCount * (uint64_t)(prop.maxThreadsPerMultiProcessor / 64);
@@ -101,6 +135,15 @@ LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
                 if (l->stream) (void)hipStreamDestroy(l->stream);
                 delete l;
                 break;
+            }
+            if (ctx->presize_kernel && !getenv("HK_NO_SCRATCH_PRESIZE")) {
+                // one wave of the deepest frame on each of the lane's streams, in creation order (see k_scratch_presize)
+                presize_fn k = (presize_fn)ctx->presize_kernel;
+                hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, l->stream, (unsigned*)nullptr, 1u);
+                for (auto& a : l->aux) hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, a, (unsigned*)nullptr, 1u);
+                bool okp = hipStreamSynchronize(l->stream) == hipSuccess;
+                for (auto& a : l->aux) okp = okp && hipStreamSynchronize(a) == hipSuccess;
+                if (!okp) { (void)hipGetLastError(); fprintf(stderr, "[hekaton] scratch pre-sizing of a lane failed\n"); }
             }
             memset(&l->timings, 0, sizeof(l->timings));
             ctx->lanes.push_back(l);
@@ -188,8 +231,10 @@ hk_status hk_ctx_create(hk_curve curve, int device_id, hk_ctx** out) {
     }
     const hk::CurveOps* ops = curve == HK_BN254 ? curve_ops_bn254() : curve_ops_bls381();
     // no environment setting may be able to exhaust the runtime's scratch pool (the abort of round 2): refuse here
-    HK_TRY(hk::scratch_budget_check(ops, prop));
+    void* presize = nullptr;
+    HK_TRY(hk::scratch_budget_check(ops, prop, &presize));
     hk_ctx* c = new hk_ctx();
+    c->presize_kernel = presize;
     c->curve = curve;
     c->device = device_id;
     c->ops = ops;

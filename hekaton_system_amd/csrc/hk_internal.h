@@ -149,6 +149,7 @@ struct hk_ctx {
     hk::NttTables* ntt = nullptr;
     hk_timings last;
     uint32_t max_lanes0 = 262144;   // level-0 accumulate lanes: 4 waves/SIMD x 1024 SIMDs x 64
+    void* presize_kernel = nullptr; // k_scratch_presize<W> with the process's deepest frame (hk_core.hip)
 };
 
 struct hk_pk {

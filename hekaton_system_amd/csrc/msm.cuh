@@ -298,6 +298,11 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 E = start[p.NB];
     LevelInfo li = msm_level_info(p, E, 0);
+    // No memset precedes this launch.  The reduction's ticket (one u32 behind the buckets) is cleared here; a bucket with
+    // no entries is never read (the reductions see start[b] == start[b + 1]); every other bucket is written exactly once by
+    // the lane in whose slice it STARTS - its sum when it also ends there, the neutral element when it continues into the
+    // next slices, whose partial sums the level kernels then add to it.
+    if (t == 0) *reinterpret_cast<u32*>(buckets + p.NB) = 0u;
     if (t >= li.active) return;
     u32 pos = t * li.L;
     u32 end = min(pos + li.L, E);
@@ -366,7 +371,7 @@ k_msm_accum0(const Affine<F>* __restrict__ bases, u32 n_bases, u32 idx_off,
     bool tail_partial = end < boundary;     // bucket b continues in the next lane's slice
     bool is_tail = false;
     if (first && head_partial) st_vec(&ppts[2 * t], acc);          // single run that began before this slice
-    else if (tail_partial) is_tail = true;
+    else if (tail_partial) { is_tail = true; st_vec(&buckets[b], XYZZ<F>::inf()); }   // starts here, continues: neutral
     else st_vec(&buckets[b], acc);
     pkeys[2 * t] = first_key;
     pkeys[2 * t + 1] = b;
@@ -447,15 +452,18 @@ k_msm_accum_tail(int level0, u32* __restrict__ keys0, XYZZ<F>* __restrict__ pts0
 // sum_b (b+1) * bucket[b] over its range = local running sum + (j*K) * (plain sum)
 template <class F>
 __global__ void __launch_bounds__(64)
-k_msm_bucket_reduce(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __restrict__ out) {
+k_msm_bucket_reduce(const XYZZ<F>* __restrict__ buckets, const u32* __restrict__ start, MsmPlan p,
+                    XYZZ<F>* __restrict__ out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 J = p.B / p.K;
     if (t >= p.WP * J) return;
     u32 w = t / J, j = t - w * J;
-    const XYZZ<F>* bk = buckets + (size_t)w * p.B + (size_t)j * p.K;
+    u32 b0 = w * p.B + j * p.K;
+    const XYZZ<F>* bk = buckets + b0;
     XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
     for (int b = (int)p.K - 1; b >= 0; b--) {
-        XYZZ<F> q = ld_vec(&bk[b]);
+        // a bucket without entries was never written (no memset): it is the neutral element
+        XYZZ<F> q = start[b0 + b] == start[b0 + b + 1] ? XYZZ<F>::inf() : ld_vec(&bk[b]);
         run = ec_add_ni(run, q);
         tot = ec_add_ni(tot, run);
     }
@@ -473,12 +481,12 @@ k_msm_bucket_reduce(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __r
 
 // WP == 1 (every table-backed MSM): bucket reduction, the sum over lanes and the final result in ONE launch.
 // Every workgroup reduces its lanes' weighted bucket sums in LDS and publishes one partial; the workgroup that
-// takes the last ticket adds the partials.  `ticket` is zeroed together with the buckets (it sits right behind them).
+// takes the last ticket adds the partials.  `ticket` sits right behind the buckets and is cleared by k_msm_accum0.
 constexpr int MSM_REDUCE_THREADS = 128;
 template <class F>
 __global__ void __launch_bounds__(MSM_REDUCE_THREADS)
-k_msm_reduce_fused(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __restrict__ partial,
-                   u32* __restrict__ ticket, XYZZ<F>* __restrict__ res) {
+k_msm_reduce_fused(const XYZZ<F>* __restrict__ buckets, const u32* __restrict__ start, MsmPlan p,
+                   XYZZ<F>* __restrict__ partial, u32* __restrict__ ticket, XYZZ<F>* __restrict__ res) {
     __shared__ XYZZ<F> sh[MSM_REDUCE_THREADS];
     __shared__ u32 last;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,9 +494,10 @@ k_msm_reduce_fused(const XYZZ<F>* __restrict__ buckets, MsmPlan p, XYZZ<F>* __re
     XYZZ<F> tot = XYZZ<F>::inf();
     if (t < J) {
         const XYZZ<F>* bk = buckets + (size_t)t * p.K;
+        const u32* st = start + (size_t)t * p.K;
         XYZZ<F> run = XYZZ<F>::inf();
         for (int b = (int)p.K - 1; b >= 0; b--) {
-            XYZZ<F> q = ld_vec(&bk[b]);
+            XYZZ<F> q = st[b] == st[b + 1] ? XYZZ<F>::inf() : ld_vec(&bk[b]);      // empty bucket: never written
             run = ec_add_ni(run, q);
             tot = ec_add_ni(tot, run);
         }

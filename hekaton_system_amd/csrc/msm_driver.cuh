@@ -27,8 +27,9 @@ template <class Fr>
 struct MsmSort {
     static hk_status alloc(Lane* L, const MsmPlan& p, SortBufs* out);
     // scalars_d: n field elements on the device (canonical, or Montgomery when is_mont)
+    // count_is_zero: the caller cleared sb.count in a kernel of its own that precedes this call in stream order
     static hk_status run(hipStream_t s, const MsmPlan& p, const u32* scalars_d, int is_mont,
-                         const SortBufs& sb);
+                         const SortBufs& sb, bool count_is_zero = false);
 };
 
 template <class F>

@@ -30,9 +30,9 @@ hk_status MsmSort<Fr>::alloc(Lane* L, const MsmPlan& p, SortBufs* out) {
 
 template <class Fr>
 hk_status MsmSort<Fr>::run(hipStream_t s, const MsmPlan& p, const u32* scalars_d, int is_mont,
-                           const SortBufs& sb) {
+                           const SortBufs& sb, bool count_is_zero) {
     if (p.NB > (u32)MSM_LDS_COUNTERS || p.c > 16) return HK_ERR_ARG;       // digits are stored as int16
-    HK_HIP(hipMemsetAsync(sb.count, 0, sizeof(u32) * p.NB, s));
+    if (!count_is_zero) HK_HIP(hipMemsetAsync(sb.count, 0, sizeof(u32) * p.NB, s));
     u32 blocks = (p.n + p.chunk - 1) / p.chunk;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL((k_msm_hist<Fr>), dim3(blocks), dim3(MSM_SORT_THREADS), 0, s,
@@ -79,7 +79,8 @@ hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p0, const Affine<F>* tabl
                          const SortBufs& sb, const Bufs& b, XYZZ<F>* result_d,
                          hipEvent_t ev0, hipEvent_t ev1) {
     const MsmPlan p = msm_lane_plan<F>(p0);
-    HK_HIP(hipMemsetAsync(b.buckets, 0, sizeof(XYZZ<F>) * (p.NB + 1), s));
+    // no memset of the buckets (4 - 8 MB per MSM): k_msm_accum0 writes every bucket that has entries and clears the
+    // ticket, the reductions skip the empty ones
     u32* ticket = reinterpret_cast<u32*>(b.buckets + p.NB);
     // with profiling on, ev0/ev1 take the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), so
     // the figure agrees with rocprofv3's kernel trace even when other lanes share the hardware queues
@@ -105,12 +106,12 @@ hk_status MsmRun<F>::run(hipStream_t s, const MsmPlan& p0, const Affine<F>* tabl
     u32 J = p.B / p.K;
     if (p.WP == 1) {
         u32 blocks = (J + MSM_REDUCE_THREADS - 1) / MSM_REDUCE_THREADS;
-        hipLaunchKernelGGL((k_msm_reduce_fused<F>), dim3(blocks), dim3(MSM_REDUCE_THREADS), 0, s, b.buckets, p, b.red,
+        hipLaunchKernelGGL((k_msm_reduce_fused<F>), dim3(blocks), dim3(MSM_REDUCE_THREADS), 0, s, b.buckets, sb.start, p, b.red,
                            ticket, result_d);
         HK_DBG(s, "k_msm_reduce_fused");
     } else {
         hipLaunchKernelGGL((k_msm_bucket_reduce<F>), dim3((p.WP * J + 63) / 64), dim3(64), 0, s,
-                           b.buckets, p, b.red);
+                           b.buckets, sb.start, p, b.red);
         HK_DBG(s, "k_msm_bucket_reduce");
         hipLaunchKernelGGL((k_msm_window_sum<F>), dim3(p.WP), dim3(MSM_WSUM_THREADS), 0, s, b.red, p, b.wsum);
         HK_DBG(s, "k_msm_window_sum");

@@ -205,13 +205,19 @@ __global__ void k_bitrev(Fr* __restrict__ data, u32 logn) {
 }
 
 // ---- R1CS -> QAP --------------------------------------------------------------------------------
-// out[row] = <M_row, z>   (ark-groth16 `evaluate_constraint`), one lane per row
+// out[row] = <M_row, z>   (ark-groth16 `evaluate_constraint`), one lane per row of the WHOLE domain vector: rows past
+// the matrix are written too - z[row - n_rows] for the n_copy instance rows of a ("a[start..end] =
+// full_assignment[..num_inputs]"), zero for the rest - so the 3 m-element vectors need no memset before the transforms
 template <class Fr>
 __global__ void k_spmv(const u64* __restrict__ row_ptr, const u32* __restrict__ col,
                        const Fr* __restrict__ val, const Fr* __restrict__ z, Fr* __restrict__ out,
-                       u32 n_rows) {
+                       u32 n_rows, u32 n_copy, u32 m) {
     u32 row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+    if (row >= m) return;
+    if (row >= n_rows) {
+        fr_store(&out[row], row - n_rows < n_copy ? fr_load(&z[row - n_rows]) : Fr::zero());
+        return;
+    }
     u64 b = row_ptr[row], e = row_ptr[row + 1];
     Fr acc = Fr::zero();
     Fr one = Fr::one();

@@ -283,16 +283,14 @@ struct QapHost {
     static hk_status run(hipStream_t s, NttTables* T, const CsrDev& A, const CsrDev& B, const CsrDev& Cm,
                          size_t n_inst, size_t n_c, const Fr* z, Fr* abc, u32 log_m) {
         size_t m = (size_t)1 << log_m;
-        HK_HIP(hipMemsetAsync(abc, 0, 3 * m * sizeof(Fr), s));
         const CsrDev* Ms[3] = {&A, &B, &Cm};
         for (int k = 0; k < 3; k++) {
-            if (Ms[k]->n_rows == 0) continue;
-            hipLaunchKernelGGL((k_spmv<Fr>), dim3((u32)((Ms[k]->n_rows + 255) / 256)), dim3(256), 0, s,
+            // every row of the m-element vector is written: matrix rows, the instance copy behind them (a only:
+            // a[n_c + j] = z[j]), zeros - no memset of the 3 m x 32 B (a 201 MB fill at m = 2^21)
+            hipLaunchKernelGGL((k_spmv<Fr>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s,
                                Ms[k]->row_ptr, Ms[k]->col, (const Fr*)Ms[k]->val, z, abc + k * m,
-                               (u32)Ms[k]->n_rows);
+                               (u32)n_c, k == 0 ? (u32)n_inst : 0u, (u32)m);
         }
-        hipLaunchKernelGGL((k_copy_inputs<Fr>), dim3((u32)((n_inst + 255) / 256)), dim3(256), 0, s, abc, z,
-                           (u32)n_c, (u32)n_inst);
         // With Z constant on the coset (Z(g w^i) = g^m - 1) and the transforms linear,
         //     h = zinv * (coset_ifft(a_coset o b_coset) - ifft(c))
         // which is bit for bit what A.1 computes with its seventh transform (c's coset fft) left out.
@@ -1230,8 +1228,16 @@ void Ops<C>::ctx_release(hk_ctx* ctx) {
 
 // ---- small device helpers for the fused calls -------------------------------------------------------------
 // ext[0] = r, ext[1] = s, ext[2] = r*s, ext[3+i] = kappa_i   (all Montgomery)
+// Also clears the bucket counters of the proof's digit sorts (up to three arrays of `nb` u32 each; every workgroup takes a
+// share): they are accumulated with atomics by k_msm_hist, and this kernel precedes every sort of the proof in stream
+// order (the side streams wait for the event recorded behind it) - three memset launches less per proof.
 template <class Fr>
-__global__ void k_prep_ext(Fr* __restrict__ ext, const Fr* __restrict__ rs_kappas, u32 n_kappas) {
+__global__ void k_prep_ext(Fr* __restrict__ ext, const Fr* __restrict__ rs_kappas, u32 n_kappas, u32* __restrict__ c0,
+                           u32* __restrict__ c1, u32* __restrict__ c2, u32 nb0, u32 nb1, u32 nb2) {
+    u32 gt = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (u32 i = gt; i < nb0; i += stride) c0[i] = 0;
+    for (u32 i = gt; i < nb1; i += stride) c1[i] = 0;
+    for (u32 i = gt; i < nb2; i += stride) c2[i] = 0;
     if (blockIdx.x || threadIdx.x) return;
     Fr r = fr_load(&rs_kappas[0]), s = fr_load(&rs_kappas[1]);
     fr_store(&ext[0], r);
@@ -1388,9 +1394,9 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     HK_HIP(hipMemcpyAsync(small, r_m, sizeof(Fr), hipMemcpyHostToDevice, s));
     HK_HIP(hipMemcpyAsync(small + 1, s_m, sizeof(Fr), hipMemcpyHostToDevice, s));
     if (n_kappas) HK_HIP(hipMemcpyAsync(small + 2, kappas, n_kappas * sizeof(Fr), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL((k_prep_ext<Fr>), dim3(1), dim3(64), 0, s, zext + (n_v - 1), small, (u32)n_kappas);
     // --- one digit sort shared by the four assignment-indexed queries
     SortBufs sb, sbh, sbb;
+    sbb.count = nullptr;
     HK_TRY(MsmSort<Fr>::alloc(L, pz, &sb));
     HK_TRY(MsmSort<Fr>::alloc(L, ph, &sbh));
     Fr* zb = nullptr;
@@ -1399,6 +1405,8 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
         zb = L->alloc_n<Fr>(pk->b_n);
         if (!zb) return HK_ERR_NOMEM;
     }
+    hipLaunchKernelGGL((k_prep_ext<Fr>), dim3(64), dim3(256), 0, s, zext + (n_v - 1), small, (u32)n_kappas, sb.count,
+                       sbh.count, sbb.count, pz.NB, ph.NB, pk->b_compact ? pb.NB : 0u);
     typename MsmRun<Fq>::Bufs rbA, rbB1, rbL, rbh;
     typename MsmRun<Fq2>::Bufs rb2;
     HK_TRY(MsmRun<Fq>::alloc(L, pz, &rbA));
@@ -1441,11 +1449,11 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     if (prof) HK_HIP(hipEventRecord(ev[5], ax[3]));
     HK_TRY(Q::run(ax[3], T, pk->csr[0], pk->csr[1], pk->csr[2], pk->n_inst, pk->n_c, zd, abc, pk->log_m));
     if (prof) HK_HIP(hipEventRecord(ev[6], ax[3]));                            // witness map done
-    HK_TRY(MsmSort<Fr>::run(ax[3], ph, (const u32*)abc, 1, sbh));
+    HK_TRY(MsmSort<Fr>::run(ax[3], ph, (const u32*)abc, 1, sbh, true));
     hipEvent_t kh0 = prof ? ev[12] : nullptr, kh1 = prof ? ev[13] : nullptr;
     HK_TRY(MsmRun<Fq>::run(ax[3], ph, pk->h_tab, (u32)m, 0, sbh, rbh, res1 + 3, kh0, kh1));
     HK_HIP(hipEventRecord(ev[7], ax[3]));                                      // H done
-    HK_TRY(MsmSort<Fr>::run(s, pz, (const u32*)zext, 1, sb));
+    HK_TRY(MsmSort<Fr>::run(s, pz, (const u32*)zext, 1, sb, true));
     HK_HIP(hipEventRecord(ev_sorted, s));
     HK_TRY(mark());                                                            // ev1: digits done
     HK_HIP(hipStreamWaitEvent(ax[2], ev_sorted, 0));
@@ -1455,7 +1463,7 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
         HK_HIP(hipStreamWaitEvent(ax[0], ev_z, 0));
         hipLaunchKernelGGL((k_gather<Fr>), dim3((pk->b_n + 255) / 256), dim3(256), 0, ax[0], zb, (const Fr*)zext,
                            (const u32*)pk->b_idx, pk->b_n, pk->n_ext);
-        HK_TRY(MsmSort<Fr>::run(ax[0], pb, (const u32*)zb, 1, sbb));
+        HK_TRY(MsmSort<Fr>::run(ax[0], pb, (const u32*)zb, 1, sbb, true));
         HK_HIP(hipEventRecord(ev[28], ax[0]));
         HK_HIP(hipStreamWaitEvent(ax[1], ev[28], 0));
         sbB = &sbb;

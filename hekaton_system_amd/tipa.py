@@ -137,11 +137,11 @@ class Tipp:
         h = len(buf) // 2
         return buf[:h], buf[h:]
 
-    def _fold(self, group, lo, hi, coeff, n):
+    def _fold(self, group, lo, hi, coeff, n, out=None):
         # the challenge split along an endomorphism: psi on G2 (66 doubling steps instead of 254), GLV's phi on G1 (128)
         if group == 2:
-            return self.ctx.points_fold_g2(lo, hi, coeff, n=n)
-        return self.ctx.points_fold_g1(lo, hi, coeff, n=n)
+            return self.ctx.points_fold_g2(lo, hi, coeff, n=n, out=out)
+        return self.ctx.points_fold_g1(lo, hi, coeff, n=n, out=out)
 
     def _powers(self, x, n):
         out = [1] * n
@@ -156,25 +156,45 @@ class Tipp:
         ctx, fc, F, r = self.ctx, self.fc, self.F, self.r
         n = srs.n
         g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
+        from .capi import DeviceBuffer
         r_inv = pow(twist, -1, r)
         tw, tw_inv = self._powers(twist, n), self._powers(r_inv, n)
-        b = ctx.scalar_pairing(2, B, fc.enc(tw), n=n)                      # B' = B^(r^i)
-        w1 = ctx.scalar_pairing(1, srs.ck.w1, fc.enc(tw_inv), n=n)         # w' = w^(r^-i)
-        w2 = ctx.scalar_pairing(1, srs.ck.w2, fc.enc(tw_inv), n=n)
-        a, v1, v2 = np.asarray(A), srs.ck.v1, srs.ck.v2
+        # The six vectors of the recursion live in HBM from here to the last round (one allocation, carved up front: a
+        # vector of m elements is followed by its folds of m/2, m/4, ... elements): a round's calls take windows of it and
+        # write the folded halves next to them, nothing is downloaded until the single final elements.
+        sizes = [g1b, g2b, g2b, g2b, g1b, g1b]                              # a, b', v1, v2, w1', w2'
+        arena = DeviceBuffer(ctx, sum(2 * n * sz for sz in sizes))
+        base, off = [], 0
+        for sz in sizes:
+            base.append(off)
+            off += 2 * n * sz
+        win = lambda k, start, count: arena.view(base[k] + start * sizes[k], count * sizes[k])
+        go = self.pool.submit
+        twb, twib = fc.enc(tw), fc.enc(tw_inv)
+        # B' = B^(r^i), w' = w^(r^-i): three independent element-wise sweeps, issued together; A, v1, v2 are copied in
+        first = [go(ctx.scalar_pairing, 2, B, twb, n, win(1, 0, n)),
+                 go(ctx.scalar_pairing, 1, srs.ck.w1, twib, n, win(4, 0, n)),
+                 go(ctx.scalar_pairing, 1, srs.ck.w2, twib, n, win(5, 0, n))]
+        for k, src in ((0, np.asarray(A)), (2, srs.ck.v1), (3, srs.ck.v2)):
+            src = np.ascontiguousarray(src, dtype=np.uint8)
+            from .capi import check, load
+            check(load().hk_dev_upload(ctx.handle, win(k, 0, n).ptr, src.ctypes.data, src.nbytes), "hk_dev_upload")
+        for f in first:
+            f.result()
         tr = Transcript(r)
         tr.absorb(b"instance", F.encode(com.t), F.encode(com.u), F.encode(z_ab), twist.to_bytes(32, "little"), n.to_bytes(8, "little"))
         rounds, challenges = [], []
-        m = n
+        m, pos = n, 0                                                       # the current vectors start at element `pos`
         while m > 1:
             h = m // 2
-            aL, aR = a[:h * g1b], a[h * g1b:]
-            bL, bR = b[:h * g2b], b[h * g2b:]
-            v1L, v1R, v2L, v2R = v1[:h * g2b], v1[h * g2b:], v2[:h * g2b], v2[h * g2b:]
-            w1L, w1R, w2L, w2R = w1[:h * g1b], w1[h * g1b:], w2[:h * g1b], w2[h * g1b:]
+            L = lambda k: win(k, pos, h)
+            R = lambda k: win(k, pos + h, h)
+            aL, aR, bL, bR = L(0), R(0), L(1), R(1)
+            v1L, v1R, v2L, v2R = L(2), R(2), L(3), R(3)
+            w1L, w1R, w2L, w2R = L(4), R(4), L(5), R(5)
             # all ten multi-pairings of the round in two batched calls, issued together
-            fa = self.pool.submit(ctx.pairing_products, [aR, aL], [v1L, v2L, bL, v1R, v2R, bR], h)
-            fw = self.pool.submit(ctx.pairing_products, [w1R, w2R, w1L, w2L], [bL, bR], h)
+            fa = go(ctx.pairing_products, [aR, aL], [v1L, v2L, bL, v1R, v2R, bR], h)
+            fw = go(ctx.pairing_products, [w1R, w2R, w1L, w2L], [bL, bR], h)
             pa, pw = fa.result(), fw.result()
             D = F.decode
             TL = F.mul(D(pa[0, 0]), D(pw[0, 0])); UL = F.mul(D(pa[0, 1]), D(pw[1, 0])); ZL = D(pa[0, 2])
@@ -184,11 +204,15 @@ class Tipp:
             c_inv = pow(c, -1, r)
             rounds.append(dict(TL=TL, UL=UL, ZL=ZL, TR=TR, UR=UR, ZR=ZR))
             challenges.append(c)
-            folds = [self.pool.submit(self._fold, *args) for args in (
-                (1, aL, aR, c, h), (2, bL, bR, c_inv, h), (2, v1L, v1R, c_inv, h), (2, v2L, v2R, c_inv, h),
-                (1, w1L, w1R, c, h), (1, w2L, w2R, c, h))]
-            a, b, v1, v2, w1, w2 = (f.result() for f in folds)
-            m = h
+            nxt = pos + m                                                   # the folds go right behind the current vectors
+            folds = [go(self._fold, g, lo, hi, cc, h, win(k, nxt, h)) for k, (g, lo, hi, cc) in enumerate((
+                (1, aL, aR, c), (2, bL, bR, c_inv), (2, v1L, v1R, c_inv), (2, v2L, v2R, c_inv),
+                (1, w1L, w1R, c), (1, w2L, w2R, c)))]
+            for f in folds:
+                f.result()
+            m, pos = h, nxt
+        a, b, v1, v2, w1, w2 = (win(k, pos, 1).to_host() for k in range(6))
+        arena.free()
         tr.absorb(b"final", a, b, v1, v2, w1, w2)
         z = tr.challenge(b"kzg-point")
         ch_rev = challenges[::-1]
@@ -199,9 +223,10 @@ class Tipp:
         fw = [0] * n + ipa_polynomial_coeffs(ch_rev, r_inv, r)
         qw = fc.enc(_divide_by_linear(fw, z, r))
         res = srs.resident
+        opens = [self.pool.submit(res[k].msm, q) for k, q in (("h_alpha", qv), ("h_beta", qv), ("g_alpha", qw), ("g_beta", qw))]
+        ov1, ov2, ow1, ow2 = (f.result() for f in opens)                   # four independent MSMs, issued together
         proof = dict(rounds=rounds, final_a=a, final_b=b, final_v=(v1, v2), final_w=(w1, w2),
-                     open_v=(res["h_alpha"].msm(qv), res["h_beta"].msm(qv)),
-                     open_w=(res["g_alpha"].msm(qw), res["g_beta"].msm(qw)))
+                     open_v=(ov1, ov2), open_w=(ow1, ow2))
         return proof
 
     # ---- verify -----------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ SCRATCH_RESERVE = 1 << 30
 DEFAULT_HW_QUEUES = 20
 WAVE_SLOTS = 256 * 32
 SERIAL_ONLY = ("k_pair_miller", "k_f12_product", "k_final_exp")
+PRESIZE = "k_scratch_presize"       # hk_core.hip: one-wave kernels that only SIZE a queue's ring to the deepest real frame
 BRANCH_REACH_BYTES = 32767 * 4      # s_cbranch_*: signed 16-bit dword offset
 
 
@@ -132,7 +133,7 @@ def main():
         print("%-6d %-5d %-5d %-7d %-6d %-9s %-4s %s" % (r["vgpr"], r["agpr"], r["sgpr"], r["scratch"], r["lds"],
                                                          "%d/%d" % (r["vgpr_spill"], r["sgpr_spill"]),
                                                          "YES" if r["dyn_stack"] else "-", name[:150]))
-        if r["dyn_stack"] or r["scratch"] > SCRATCH_LIMIT_BYTES:
+        if r["dyn_stack"] or (r["scratch"] > SCRATCH_LIMIT_BYTES and PRESIZE not in name):
             bad.append(name)
     fdm = demangle([f[2] for f in funcs]) if funcs else {}
     big = sorted({(sz, k, fdm[n]) for sz, k, n in funcs if sz > BRANCH_REACH_BYTES}, reverse=True)
@@ -145,9 +146,12 @@ def main():
             bad.append("device function larger than the s_cbranch reach (%d B): %s" % (sz, n))
     if check and n_getpc:
         bad.append("%d long branch(es) through the return-address pair s[30:31]" % n_getpc)
-    deep = max((r for r in rows if not any(k in dm[r["symbol"]] for k in SERIAL_ONLY)), key=lambda r: r["scratch"], default=None)
+    deep = max((r for r in rows if not any(k in dm[r["symbol"]] for k in SERIAL_ONLY + (PRESIZE,))), key=lambda r: r["scratch"],
+               default=None)
     if deep:
-        ring = deep["scratch"] * 64 * WAVE_SLOTS
+        presized = min((r["scratch"] for r in rows if PRESIZE in dm[r["symbol"]] and r["scratch"] >= deep["scratch"]),
+                       default=deep["scratch"])          # what hk_ctx_create sizes every ring to
+        ring = presized * 64 * WAVE_SLOTS
         need = DEFAULT_HW_QUEUES * ring + SCRATCH_RESERVE
         print("scratch budget of the default configuration: deepest default-path frame %d B (%s) -> ring %.2f GiB per queue; "
               "%d queues + reserve = %.1f GiB of %d GiB" % (deep["scratch"], re.sub(r"\(.*", "", dm[deep["symbol"]])[:60], ring / 2**30,
@@ -172,7 +176,7 @@ def main():
     if check:
         print("kernel_meta --check ok: %d kernels, no dynamic stack, max scratch %d B per lane (limit %d), no device "
               "function above the s_cbranch reach, no s[30:31] long branch, no half-defined VGPR read at an if / else "
-              "join" % (len(rows), max(r["scratch"] for r in rows), SCRATCH_LIMIT_BYTES))
+              "join" % (len(rows), max(r["scratch"] for r in rows if PRESIZE not in dm[r["symbol"]]), SCRATCH_LIMIT_BYTES))
 
 
 if __name__ == "__main__":
