@@ -539,13 +539,16 @@ def roofline_of(job, curve):
     avg_ms = float(np.sum(job.accum_ms) / max(1, np.sum(job.accum_n))) if job.accum_ms else float("nan")
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     h_ms = float(np.mean(job.accum_h)) if job.accum_h else float("nan")
-    traffic = None
-    try:      # HBM traffic of the same kernel from separate rocprofv3 --pmc passes (cannot be read live)
+    traffic, traffic_source = None, None
+    try:      # HBM traffic of the same kernel from separate rocprofv3 --pmc passes (cannot be read live): a COMMITTED
+        # measurement of an earlier build of this kernel, labelled as such
         with open(os.path.join(ROOT, "profiles", "pmc_accum0.json")) as f:
             pmc = json.load(f)
         key = "%s/%s" % (job.args.config, curve)
         if key in pmc:
             traffic = (pmc[key]["FETCH_SIZE_KiB_avg"] + pmc[key]["WRITE_SIZE_KiB_avg"]) * 1024.0
+            traffic_source = "profiles/pmc_accum0.json (%s): FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc " \
+                             "passes, not read during this run" % pmc.get("_collected", "collection not recorded")
     except Exception:       # noqa: BLE001
         pass
     alone = None
@@ -554,8 +557,12 @@ def roofline_of(job, curve):
         ah = float(np.mean([t["accum_h_ms"] for t in al]))
         aavg = float(np.sum([t["accum_kernel_ms"] for t in al]) / max(1, np.sum([t["accum_kernel_launches"] for t in al])))
         ap = (m - 1) * nwin * 10 / (ah * 1e-3) / 1e9
-        alone = {"note": "the same kernel with ONE proof on the GPU (sequential proofs on one lane, after the timed region)",
-                 "avg_launch_ms": aavg, "achieved": alg_bytes / (aavg * 1e-3) / 1e9, "frac": alg_bytes / (aavg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # the uncontended proofs run stage 1 only: the same 4 launches (H, A, B1, L) on both sides of the division
+        alg4 = sum(terms[:4]) * (32 + g1) / 4
+        alone = {"note": "the same kernel with ONE proof on the GPU (sequential stage-1 proofs on one lane, after the timed "
+                         "region); bytes and time both over its 4 launches per proof (H, A, B1, L)",
+                 "avg_launch_ms": aavg, "alg_bytes_per_launch": alg4, "achieved": alg4 / (aavg * 1e-3) / 1e9,
+                 "frac": alg4 / (aavg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "h_query_ms": ah, "valu_achieved": ap, "valu_frac": ap / VALU_PRODUCT_CEILING[curve],
                  "proof_latency_ms": float(np.mean([t["total_ms"] for t in al]))}
     prods = (m - 1) * nwin * 10 / (h_ms * 1e-3) / 1e9
@@ -565,7 +572,7 @@ def roofline_of(job, curve):
         "kernel": "k_msm_accum0<Fp<%s>> (bucket accumulation; avg over its 5 launches per subcircuit)" % (
             "Bn254FqP" if curve == "bn254" else "Bls381FqP"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+        "traffic": traffic, "traffic_source": traffic_source, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
         "proofs_in_flight": job.args.threads, "alone": alone,
         "h_query_launch": {"alg_bytes": (m - 1) * (32 + g1), "avg_ms": h_ms,
                            "achieved": (m - 1) * (32 + g1) / (h_ms * 1e-3) / 1e9},

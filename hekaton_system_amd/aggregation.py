@@ -156,7 +156,7 @@ class AggProvingKey:
         self.ctx, self.curve, self.ck = ctx, curve, ck
         self.com = TIPPCommitment(ctx, curve)
         self.F = self.com.F
-        self.pool = ThreadPoolExecutor(max_workers=6)
+        self.pool = ThreadPoolExecutor(max_workers=12)
         g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
         cat = lambda xs: np.concatenate([np.asarray(x, np.uint8) for x in xs])
         self.n = len(vks)
@@ -232,13 +232,29 @@ class AggProvingKey:
             s = pt.challenge_scalar(b"s-random-fiatshamir", r_mod)
             t = pt.challenge_scalar(b"t-random-fiatshamir", r_mod)
         s2, s3, t2, t3 = s * s % r_mod, s * s * s % r_mod, t * t % r_mod, t * t * t % r_mod
-        f_left = go(ctx.points_lincomb, 1, [a_vals, prepared_input, d_vals, c_vals], fc.enc([1, s, s2, s3]), n)       # :293-310
-        f_right = go(ctx.points_lincomb, 2, [b_vals, self.h, self.delta0, self.delta1], fc.enc([1, t, t2, t3]), n)    # :311-326
+        # left = A + S^s + D^(s^2) + C^(s^3), right = B + H^t + ... (:293-326: three `scalar_pairing` sweeps with a constant
+        # scalar and element-wise additions each).  The three products of a side are independent: each runs as its own
+        # endomorphism-split chain (hk_points_fold: 128 / 66 doubling steps) on its own lane, then one element-wise sum -
+        # instead of one joint 254-step chain per side (4.5 ms G1 / 13 ms G2).
+        zero1, zero2 = np.zeros(n * ctx.g1_bytes, np.uint8), np.zeros(n * ctx.g2_bytes, np.uint8)
+        fl = [go(ctx.points_fold_g1, zero1, v, c, n) for v, c in ((prepared_input, s), (d_vals, s2), (c_vals, s3))]
+        fr = [go(ctx.points_fold_g2, zero2, v, c, n) for v, c in ((self.h, t), (self.delta0, t2), (self.delta1, t3))]
         f_lr = go(IppCom.lincomb, [(com_ab, None), (com_prepared_input, s), (com_d, s2), (com_c, s3),
                                    (self.com_h, t), (self.com_delta0, t2), (self.com_delta1, t3)])  # :328-332
+        # z_lr = twisted_inner_product(left, right) (:334) = prod_ij cross[i][j]^(s^i t^j) by bilinearity - the cross terms
+        # ARE the pairings of the twisted components (:255-263) - so it costs 16 GT powers in one batched call instead of
+        # another element-wise sweep and another N-pair multi-pairing; the same GT element, bit for bit
+        exps = [pow(s, i, r_mod) * pow(t, j, r_mod) % r_mod for i in range(4) for j in range(4)]
+        f_z = go(ctx.gt_pow, np.frombuffer(b"".join(F.encode(z[i][j]) for i in range(4) for j in range(4)), np.uint8),
+                 fc.enc(exps))
+        ones = fc.enc([1, 1, 1, 1])
+        f_left = go(lambda: ctx.points_lincomb(1, [a_vals] + [f.result() for f in fl], ones, n))
+        f_right = go(lambda: ctx.points_lincomb(2, [b_vals] + [f.result() for f in fr], ones, n))
+        pw = f_z.result()
+        z_lr = F.one
+        for k in range(16):
+            z_lr = F.mul(z_lr, F.decode(pw[k]))
         left, right = f_left.result(), f_right.result()
-        left_r = ctx.scalar_pairing(1, left, twb, n=n)                                              # twisted_inner_product
-        z_lr = F.decode(ctx.multi_pairing(left_r, right, n=n))                                      # :334
         com_lr = f_lr.result()
         return dict(size=n, output=z_lr, commitment=com_lr, twist=twist, left=left, right=right, cross_terms=z,
                     com_ab=com_ab, com_c=com_c, prepared_input=prepared_input)

@@ -55,8 +55,9 @@ struct MsmRun {
                                 u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out);
     static hk_status batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, F* pref, u32 n);
     // out[i] = scalars[i] * points[i] (pairing_ops.rs:32-39); xy / pref: n-element scratch
+    // img: EndoOf<F>::K x n affine scratch for the endomorphism images (nullptr: the plain 254-step ladder)
     static hk_status scalar_mul_each(hipStream_t s, const Affine<F>* pts, const void* scalars_mont, u32 n,
-                                     XYZZ<F>* xy, F* pref, Affine<F>* out);
+                                     XYZZ<F>* xy, F* pref, Affine<F>* out, Affine<F>* img = nullptr);
     // out[i] = sum_j coeffs[j] * vecs[j][i], k <= LINCOMB_MAX (aggregation.rs:192-203,293-326)
     static hk_status lincomb(hipStream_t s, const Affine<F>* const* vecs, const void* coeffs_mont, u32 k, u32 n,
                              XYZZ<F>* xy, F* pref, Affine<F>* out);

@@ -797,7 +797,7 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
     if (!L) return HK_ERR_DEVICE;
     auto run = [&](auto ftag) -> hk_status {
         typedef decltype(ftag) F;
-        size_t need = al256(n * sizeof(Affine<F>)) * 2 + al256(n * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
+        size_t need = al256(n * sizeof(Affine<F>)) * 6 + al256(n * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
                       al256(n * sizeof(F)) + 8192;
         HK_TRY(L->reserve(need));
         const void *pd, *sd;
@@ -805,10 +805,11 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
         HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sd));
         XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
         F* pref = L->alloc_n<F>(n);
+        Affine<F>* img = L->alloc_n<Affine<F>>(4 * n);          // endomorphism images (2 used for G1, 4 for G2)
         bool out_dev = is_device_ptr(out);
         Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
-        if (!xy || !pref || !od) return HK_ERR_NOMEM;
-        HK_TRY(MsmRun<F>::scalar_mul_each(L->stream, (const Affine<F>*)pd, sd, (u32)n, xy, pref, od));
+        if (!xy || !pref || !od || !img) return HK_ERR_NOMEM;
+        HK_TRY(MsmRun<F>::scalar_mul_each(L->stream, (const Affine<F>*)pd, sd, (u32)n, xy, pref, od, img));
         if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
         HK_HIP(hipStreamSynchronize(L->stream));
         return HK_OK;
@@ -1084,7 +1085,9 @@ hk_status Ops<C>::poseidon_path(hk_ctx* ctx, const void* consts, size_t n_consts
             (size_t)d->consts_offset + (size_t)(d->full_rounds + d->partial_rounds) * d->t + (size_t)d->t * d->t > n_consts)
             return HK_ERR_ARG;
     }
-    if (lh->t != 4 || nh->t != 3) return HK_ERR_ARG;                   // rate 3 over the 4 leaf fields, rate 2 for two-to-one
+    // the kernel is compiled for the reference's two instances (poseidon_util.rs:53-62): rate 3 / x^5 over the 4 leaf
+    // fields, rate 2 / x^17 for two-to-one; round counts and constants stay run-time data
+    if (lh->t != 4 || nh->t != 3 || lh->alpha != 5 || nh->alpha != 17) return HK_ERR_ARG;
     size_t block = 2 * per_perm(lh) + depth * (3 + per_perm(nh));
     if (col0 > n_v || block > n_v - col0) return HK_ERR_ARG;
     LaneGuard g(ctx);

@@ -104,35 +104,44 @@ __global__ void k_scatter_full_batch(const u32* __restrict__ cols, const Fr* __r
 // S-box exponent 5 or 17, rf full and rp partial rounds; consts = ark[(rf + rp)][t] then mds[t][t], Montgomery.
 struct PoseidonDesc { u32 t, alpha, rf, rp, off; };
 
-template <class Fr>
-__device__ __forceinline__ void poseidon_permute_trace(const Fr* __restrict__ consts, const PoseidonDesc& d, Fr (&s)[4],
+// Width and S-box exponent are template parameters: the state, the round's S-box outputs and the MDS row sums stay in
+// registers (with runtime widths they were runtime-indexed arrays in private memory and the block took 20 ms per step).
+template <class Fr, int T, int ALPHA>
+__device__ __forceinline__ void poseidon_permute_trace(const Fr* __restrict__ consts, const PoseidonDesc& d, Fr (&s)[T],
                                                        Fr*& w) {
     const Fr* ark = consts + d.off;
-    const Fr* mds = ark + (size_t)(d.rf + d.rp) * d.t;
+    const Fr* mds = ark + (size_t)(d.rf + d.rp) * T;
     const u32 half = d.rf / 2;
-    for (u32 r = 0; r < d.rf + d.rp; r++) {
+    Fr m[T * T];
+#pragma unroll
+    for (int i = 0; i < T * T; i++) m[i] = fr_load(&mds[i]);
+    HK_NOUNROLL for (u32 r = 0; r < d.rf + d.rp; r++) {
         bool full = r < half || r >= half + d.rp;
-        Fr y[4];
-        for (u32 i = 0; i < d.t; i++) y[i] = Fr::add(s[i], fr_load(&ark[r * d.t + i]));
-        u32 nsb = full ? d.t : 1u;
-        for (u32 i = 0; i < nsb; i++) {
-            Fr u = y[i];
-            Fr x = Fr::mul(u, u);                       // u^2
-            fr_store(w++, x);
-            u32 squarings = d.alpha == 5 ? 1u : 3u;     // 5: u^2 u^4 u^5; 17: u^2 u^4 u^8 u^16 u^17
-            for (u32 k = 0; k < squarings; k++) { x = Fr::mul(x, x); fr_store(w++, x); }
-            x = Fr::mul(x, u);
-            fr_store(w++, x);
-            y[i] = x;
+        Fr y[T];
+#pragma unroll
+        for (int i = 0; i < T; i++) y[i] = Fr::add(s[i], fr_load(&ark[r * T + i]));
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            if (i == 0 || full) {
+                Fr u = y[i];
+                Fr x = Fr::mul(u, u);                       // u^2
+                fr_store(w++, x);
+#pragma unroll
+                for (int k = 0; k < (ALPHA == 5 ? 1 : 3); k++) { x = Fr::mul(x, x); fr_store(w++, x); }   // u^4 (u^8 u^16)
+                x = Fr::mul(x, u);                          // u^5 / u^17
+                fr_store(w++, x);
+                y[i] = x;
+            }
         }
-        Fr n[4];
-        for (u32 i = 0; i < d.t; i++) {
-            Fr acc = Fr::mul(fr_load(&mds[i * d.t]), y[0]);
-            for (u32 j = 1; j < d.t; j++) acc = Fr::add(acc, Fr::mul(fr_load(&mds[i * d.t + j]), y[j]));
-            n[i] = acc;
-            fr_store(w++, acc);
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            Fr acc = Fr::mul(m[i * T], y[0]);
+#pragma unroll
+            for (int j = 1; j < T; j++) acc = Fr::add(acc, Fr::mul(m[i * T + j], y[j]));
+            s[i] = acc;
         }
-        for (u32 i = 0; i < d.t; i++) s[i] = n[i];
+#pragma unroll
+        for (int i = 0; i < T; i++) fr_store(w++, s[i]);
     }
 }
 
@@ -151,21 +160,22 @@ k_poseidon_path(const Fr* __restrict__ consts, PoseidonDesc leaf_d, PoseidonDesc
     Fr s[4];
     s[0] = Fr::zero();
     for (u32 i = 0; i < 3; i++) s[1 + i] = fr_load(&leaf[(size_t)b * 4 + i]);
-    poseidon_permute_trace<Fr>(consts, leaf_d, s, w);
+    poseidon_permute_trace<Fr, 4, 5>(consts, leaf_d, s, w);
     s[1] = Fr::add(s[1], fr_load(&leaf[(size_t)b * 4 + 3]));
-    poseidon_permute_trace<Fr>(consts, leaf_d, s, w);
+    poseidon_permute_trace<Fr, 4, 5>(consts, leaf_d, s, w);
     Fr cur = s[1];
     u32 idx = index[b];
-    for (u32 l = 0; l < depth; l++) {
+    HK_NOUNROLL for (u32 l = 0; l < depth; l++) {
         Fr sib = fr_load(&siblings[(size_t)b * depth + l]);
         bool bit = (idx >> l) & 1u;
         Fr left = bit ? sib : cur, right = bit ? cur : sib;
         fr_store(w++, bit ? Fr::one() : Fr::zero());
         fr_store(w++, sib);
         fr_store(w++, left);
-        s[0] = Fr::zero(); s[1] = left; s[2] = right; s[3] = Fr::zero();
-        poseidon_permute_trace<Fr>(consts, node_d, s, w);
-        cur = s[1];
+        Fr t3[3];
+        t3[0] = Fr::zero(); t3[1] = left; t3[2] = right;
+        poseidon_permute_trace<Fr, 3, 17>(consts, node_d, t3, w);
+        cur = t3[1];
     }
 }
 

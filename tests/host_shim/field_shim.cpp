@@ -3,6 +3,7 @@
 #include "../../hekaton_system_amd/csrc/ec.cuh"
 #include "../../hekaton_system_amd/csrc/pairing.cuh"
 #include "../../hekaton_system_amd/csrc/msm.cuh"
+#include "../../hekaton_system_amd/csrc/endo.cuh"
 #include <string.h>
 using namespace hk;
 
@@ -101,6 +102,24 @@ void shim_group_op(int group, int op, const void* a, const void* b, void* out) {
         case 2: group_op<Fp<Bls381FqP>>(op, a, b, out); break;
         case 3: group_op<Fp2<Bls381FqP>>(op, a, b, out); break;
     }
+}
+// the device-side scalar split of csrc/endo.cuh.  group: 1 (phi, 2 parts) or 2 (psi, 4 parts); c: canonical scalar, 8 limbs;
+// mag: parts x 6 limbs; returns the sign mask
+unsigned shim_endo_decompose(int curve, int group, const unsigned* c, unsigned* mag) {
+    u32 cc[8];
+    for (int i = 0; i < 8; i++) cc[i] = c[i];
+    if (group == 1) {
+        EndoSplit<2> E = curve == 0 ? endo_split_g1((const Bn254FqP*)nullptr) : endo_split_g1((const Bls381FqP*)nullptr);
+        u32 m[2][6];
+        u32 neg = endo_decompose<2>(cc, E, m);
+        memcpy(mag, m, sizeof(m));
+        return neg;
+    }
+    EndoSplit<4> E = curve == 0 ? endo_split_g2((const Bn254FqP*)nullptr) : endo_split_g2((const Bls381FqP*)nullptr);
+    u32 m[4][6];
+    u32 neg = endo_decompose<4>(cc, E, m);
+    memcpy(mag, m, sizeof(m));
+    return neg;
 }
 // the MSM schedule (host code of csrc/msm.cuh): windows, buckets, level lanes of a plan
 // out[0..5] = W, F, NB, n_levels, T[0], chunk; curve: 0 bn254, 1 bls12-381

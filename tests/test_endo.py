@@ -86,3 +86,36 @@ def test_g1_endomorphism_eigenvalue_and_two_part_split(name):
     for c in [0, 1, cp.r - 1, P.lam, cp.r - P.lam] + [rnd.randrange(cp.r) for _ in range(500)]:
         k = P.decompose(c)
         assert (k[0] + k[1] * P.lam) % cp.r == c % cp.r and max(abs(x) for x in k).bit_length() <= 129
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_device_side_split_recombines_and_is_short(name, tmp_path_factory):
+    """csrc/endo.cuh `endo_decompose` (the split k_scalar_mul_endo runs per element, host-compiled here): for phi (2 parts)
+    and psi (4 parts), sum_j (+-)|k_j| lambda^j = c mod r for edge and random scalars, and the parts fit the kernel's fixed
+    chain lengths (131 / 68 doublings)."""
+    import ctypes
+    import os
+    import subprocess
+    import numpy as np
+    from hekaton_system_amd.endo import phi2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path_factory.mktemp("shim") / "field_shim.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", out,
+                           os.path.join(root, "tests", "host_shim", "field_shim.cpp")])
+    lib = ctypes.CDLL(out)
+    lib.shim_endo_decompose.restype = ctypes.c_uint
+    cid = 0 if name == "bn254" else 1
+    r = CURVES[name].r
+    rnd = random.Random(12)
+    for group, E, parts, bits in ((1, phi2(name), 2, 131), (2, psi4(name), 4, 68)):
+        lam = E.lam
+        for c in [0, 1, 2, r - 1, r - 2, lam, r - lam, (1 << 128) - 1, 1 << 253] + [rnd.randrange(r) for _ in range(400)]:
+            cl = np.array([(c >> (32 * i)) & 0xffffffff for i in range(8)], np.uint32)
+            mag = np.zeros(parts * 6, np.uint32)
+            neg = lib.shim_endo_decompose(cid, group, cl.ctypes.data_as(ctypes.c_void_p), mag.ctypes.data_as(ctypes.c_void_p))
+            ks = []
+            for j in range(parts):
+                m = sum(int(mag[6 * j + l]) << (32 * l) for l in range(6))
+                assert m.bit_length() <= bits, (name, group, c, j, m.bit_length())
+                ks.append(-m if (neg >> j) & 1 else m)
+            assert sum(k * pow(lam, j, r) for j, k in enumerate(ks)) % r == c % r, (name, group, c)

@@ -84,3 +84,34 @@ def test_infinity_lanes_through_phi_and_its_negations(cname, ctx_bn254, ctx_bls)
                 assert np.array_equal(got, first[c]), (cname, rep, c, "not deterministic")
             else:
                 first[c] = got.copy()
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "bn254"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_scalar_pairing_over_the_endomorphism_equals_the_oracle(cname, group, ctx_bn254, ctx_bls):
+    """hk_scalar_pairing (k_scalar_mul_endo: the scalar split on the device along phi / psi) against the oracle's scalar
+    multiplication, element by element: edge scalars (0, 1, r - 1, the eigenvalue, 2^128 - 1), infinity points, powers of
+    one value as `structured_scalar_power` makes them (aggregation.rs:224), random scalars."""
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    cp, fc, cd = CURVES[cname], FrCodec(cname), Codec(CURVES[cname])
+    G = curve.G1(cp) if group == 1 else curve.G2(cp)
+    gen = cp.g1_gen if group == 1 else cp.g2_gen
+    pb = ctx.g1_bytes if group == 1 else ctx.g2_bytes
+    dec = cd.g1_from if group == 1 else cd.g2_from
+    rnd = random.Random(5 + group)
+    lam = (phi2(cname) if group == 1 else psi4(cname)).lam
+    tw = rnd.randrange(2, cp.r)
+    scalars = [0, 1, cp.r - 1, lam, cp.r - lam, (1 << 128) - 1, 2] + [pow(tw, i, cp.r) for i in range(20)] + \
+              [rnd.randrange(cp.r) for _ in range(43)]
+    n = len(scalars)
+    ks = [rnd.randrange(1, cp.r) for _ in range(n)]
+    pts_b = ctx.fixed_base(group, (cd.g1_vec if group == 1 else cd.g2_vec)([gen]), fc.enc(ks)).copy()
+    pts_b[9 * pb:10 * pb] = 0                                    # an infinity point with a non-trivial scalar
+    got = ctx.scalar_pairing(group, pts_b, fc.enc(scalars), n=n)
+    for i in range(n):
+        have = dec(got[i * pb:(i + 1) * pb])
+        if i == 9 or scalars[i] == 0:
+            assert have is None, (cname, group, i)
+            continue
+        want = G.mul(G.mul(gen, ks[i]), scalars[i])
+        assert have == (want[0], want[1]), (cname, group, i, scalars[i])
