@@ -112,6 +112,8 @@ struct Ops {
     static hk_status msm_bases(hk_ctx*, const hk_bases*, const void*, size_t, int, int, void*);
     static hk_status pairing_products(hk_ctx*, const void* const*, size_t, const void* const*, size_t, size_t, void*);
     static hk_status points_lincomb(hk_ctx*, int, const void* const*, const void*, size_t, size_t, void*);
+    template <class F>
+    static hk_status points_fold(hk_ctx*, const void*, const void*, const void*, unsigned, size_t, void*);
     static hk_status points_fold_g2(hk_ctx*, const void*, const void*, const void*, unsigned, size_t, void*);
     static hk_status points_fold_g1(hk_ctx*, const void*, const void*, const void*, unsigned, size_t, void*);
     static hk_status assignment_from_bits(hk_ctx*, const void*, size_t, const uint32_t*, const void*, size_t, void*);

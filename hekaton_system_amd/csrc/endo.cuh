@@ -113,11 +113,15 @@ HK_HD u32 endo_decompose(const u32 (&c)[8], const EndoSplit<K>& E, u32 (&mag)[K]
 }
 
 #if defined(__HIPCC__)
-// img: K x n affine scratch (the endomorphism images of every point, sign applied), out: n XYZZ
+// tab: 2^K x n XYZZ scratch.  The lanes of a wavefront hold DIFFERENT scalars, so a "madd when bit j is set" executes for
+// the whole wave whenever any lane has the bit: with four images that was four mixed adds per step for every lane
+// (68 x (dbl + 4 madd): 7.5 ms in G2).  Each lane therefore first tabulates the 2^K - 1 subset sums of its images
+// (tab[mask][i] = sum of +-endo^j(P_i) over the bits of mask) and the chain adds ONE table entry per step, picked by the
+// column of the K sub-scalars: 68 x (dbl + add).
 template <class Fr, class F>
 __global__ void __launch_bounds__(64)
 k_scalar_mul_endo(const Affine<F>* __restrict__ pts, const Fr* __restrict__ scalars, u32 n,
-                  EndoSplit<EndoOf<F>::K> E, Affine<F>* __restrict__ img, XYZZ<F>* __restrict__ out) {
+                  EndoSplit<EndoOf<F>::K> E, XYZZ<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
     constexpr int K = EndoOf<F>::K;
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -132,15 +136,60 @@ k_scalar_mul_endo(const Affine<F>* __restrict__ pts, const Fr* __restrict__ scal
         if (j) q = EndoOf<F>::apply(q);
         Affine<F> w = q;
         if ((neg >> j) & 1u) w.y = F::neg(w.y);
-        st_vec(&img[(size_t)j * n + i], w);
+        // every mask whose TOP bit is j: the entry without that bit (already there) plus this image
+        st_vec(&tab[((size_t)1 << j) * n + i], XYZZ<F>::from_affine(w));
+        HK_NOUNROLL for (u32 m = 1; m < (1u << j); m++)
+            st_vec(&tab[(((size_t)1 << j) | m) * n + i], ec_madd_ni(ld_vec(&tab[(size_t)m * n + i]), w));
     }
     XYZZ<F> acc = XYZZ<F>::inf();
     HK_NOUNROLL for (int b = EndoOf<F>::STEPS - 1; b >= 0; b--) {
         acc = ec_dbl_ni(acc);
-        HK_NOUNROLL for (int j = 0; j < K; j++)
-            if ((mag[j][b >> 5] >> (b & 31)) & 1u) acc = ec_madd_ni(acc, ld_vec(&img[(size_t)j * n + i]));
+        u32 m = 0;
+        HK_UNROLL for (int j = 0; j < K; j++) m |= ((mag[j][b >> 5] >> (b & 31)) & 1u) << j;
+        if (m) acc = ec_add_ni(acc, ld_vec(&tab[(size_t)m * n + i]));
     }
     st_vec(&out[i], acc);
+}
+
+// out[i] = lo[i] + c * hi[i] with ONE scalar c for the whole vector, already split on the host (hekaton_system_amd/endo.py)
+// into K magnitudes and a sign mask: the fold of a TIPA round (hk_points_fold_g1 / _g2).  Same table-driven chain as
+// k_scalar_mul_endo - the endomorphism images and their subset sums are built per element inside this launch (no
+// separate image kernel, no image vectors in HBM), one table add per step - then + lo.
+// coeffs: K Montgomery Fr (the magnitudes); steps: bit length of the longest magnitude.
+template <class Fr, class F>
+__global__ void __launch_bounds__(64)
+k_points_fold_endo(const Affine<F>* __restrict__ lo, const Affine<F>* __restrict__ hi, const Fr* __restrict__ coeffs, u32 neg,
+                   u32 n, XYZZ<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
+    constexpr int K = EndoOf<F>::K;
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr mag[K];
+    int top = -1;
+    HK_UNROLL for (int j = 0; j < K; j++) {
+        mag[j] = Fr::from_mont(ld_vec(&coeffs[j]));
+        for (int b = Fr::N * 32 - 1; b > top; b--)
+            if ((mag[j].v[b >> 5] >> (b & 31)) & 1u) { top = b; break; }
+    }
+    Affine<F> l = ld_vec(&lo[i]);
+    Affine<F> q = ld_vec(&hi[i]);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (!q.is_inf()) {
+        HK_NOUNROLL for (int j = 0; j < K; j++) {
+            if (j) q = EndoOf<F>::apply(q);
+            Affine<F> w = q;
+            if ((neg >> j) & 1u) w.y = F::neg(w.y);
+            st_vec(&tab[((size_t)1 << j) * n + i], XYZZ<F>::from_affine(w));
+            HK_NOUNROLL for (u32 m = 1; m < (1u << j); m++)
+                st_vec(&tab[(((size_t)1 << j) | m) * n + i], ec_madd_ni(ld_vec(&tab[(size_t)m * n + i]), w));
+        }
+        HK_NOUNROLL for (int b = top; b >= 0; b--) {
+            acc = ec_dbl_ni(acc);
+            u32 m = 0;
+            HK_UNROLL for (int j = 0; j < K; j++) m |= ((mag[j].v[b >> 5] >> (b & 31)) & 1u) << j;
+            if (m) acc = ec_add_ni(acc, ld_vec(&tab[(size_t)m * n + i]));
+        }
+    }
+    st_vec(&out[i], ec_madd_ni(acc, l));
 }
 #endif
 

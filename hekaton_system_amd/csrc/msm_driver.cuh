@@ -55,12 +55,17 @@ struct MsmRun {
                                 u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out);
     static hk_status batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, F* pref, u32 n);
     // out[i] = scalars[i] * points[i] (pairing_ops.rs:32-39); xy / pref: n-element scratch
-    // img: EndoOf<F>::K x n affine scratch for the endomorphism images (nullptr: the plain 254-step ladder)
+    // tab: 2^K x n XYZZ scratch (K = 2 in G1, 4 in G2) for the subset sums of the endomorphism images (nullptr: the plain
+    // 254-step ladder)
     static hk_status scalar_mul_each(hipStream_t s, const Affine<F>* pts, const void* scalars_mont, u32 n,
-                                     XYZZ<F>* xy, F* pref, Affine<F>* out, Affine<F>* img = nullptr);
+                                     XYZZ<F>* xy, F* pref, Affine<F>* out, XYZZ<F>* tab = nullptr);
     // out[i] = sum_j coeffs[j] * vecs[j][i], k <= LINCOMB_MAX (aggregation.rs:192-203,293-326)
     static hk_status lincomb(hipStream_t s, const Affine<F>* const* vecs, const void* coeffs_mont, u32 k, u32 n,
                              XYZZ<F>* xy, F* pref, Affine<F>* out);
+    // out[i] = lo[i] + c * hi[i], c given as EndoOf<F>::K magnitudes (Montgomery Fr) and a sign mask (endo.cuh
+    // k_points_fold_endo); tab: 2^K x n XYZZ scratch
+    static hk_status fold_endo(hipStream_t s, const Affine<F>* lo, const Affine<F>* hi, const void* coeffs_mont, u32 neg_mask,
+                               u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out);
     // largest private-memory ("scratch") frame per lane among this flavour's kernels, from the loaded code object
     // (hipFuncGetAttributes): what sizes a hardware queue's scratch ring
     static size_t max_private_bytes();

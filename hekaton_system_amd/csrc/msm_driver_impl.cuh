@@ -131,7 +131,7 @@ size_t MsmRun<F>::max_private_bytes() {
                         (const void*)k_msm_reduce_fused<F>, (const void*)k_msm_bucket_reduce<F>,
                         (const void*)k_msm_window_sum<F>, (const void*)k_msm_final<F>, (const void*)k_to_affine<F>,
                         (const void*)k_msm_build_tables<F>, (const void*)k_batch_affine<F>, (const void*)k_fb_table<F>,
-                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>,
+                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>, (const void*)k_points_fold_endo<Fr, F>,
                         (const void*)k_points_lincomb<Fr, F>};
     size_t m = 0;
     for (const void* k : ks) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }
@@ -166,19 +166,30 @@ hk_status MsmRun<F>::batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* o
 
 template <class F>
 hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const void* scalars_mont, u32 n,
-                                     XYZZ<F>* xy, F* pref, Affine<F>* out, Affine<F>* img) {
+                                     XYZZ<F>* xy, F* pref, Affine<F>* out, XYZZ<F>* tab) {
     typedef typename ScalarOf<F>::type Fr;
     if (n == 0) return HK_OK;
     static const bool plain = getenv("HK_SCALAR_MUL_PLAIN") != nullptr;      // the 254-step ladder (A/B, debugging)
-    if (img && !plain) {
+    if (tab && !plain) {
         // scalars split on the device along phi / psi: one shared chain of 131 (G1) / 68 (G2) doublings (endo.cuh)
         static const auto E = EndoOf<F>::split();
         hipLaunchKernelGGL((k_scalar_mul_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, pts, (const Fr*)scalars_mont, n, E,
-                           img, xy);
+                           tab, xy);
     } else {
         hipLaunchKernelGGL((k_scalar_mul_each<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, pts, (const Fr*)scalars_mont,
                            n, xy);
     }
+    HK_HIP(hipGetLastError());
+    return batch_affine(s, xy, out, pref, n);
+}
+
+template <class F>
+hk_status MsmRun<F>::fold_endo(hipStream_t s, const Affine<F>* lo, const Affine<F>* hi, const void* coeffs_mont, u32 neg_mask,
+                               u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out) {
+    typedef typename ScalarOf<F>::type Fr;
+    if (n == 0) return HK_OK;
+    hipLaunchKernelGGL((k_points_fold_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, lo, hi, (const Fr*)coeffs_mont,
+                       neg_mask, n, tab, xy);
     HK_HIP(hipGetLastError());
     return batch_affine(s, xy, out, pref, n);
 }

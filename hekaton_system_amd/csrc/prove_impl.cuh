@@ -16,6 +16,7 @@
 #include "ntt.cuh"
 #include "fixed_base.cuh"
 #include "witness.cuh"
+#include "endo.cuh"
 
 namespace hk {
 
@@ -797,7 +798,7 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
     if (!L) return HK_ERR_DEVICE;
     auto run = [&](auto ftag) -> hk_status {
         typedef decltype(ftag) F;
-        size_t need = al256(n * sizeof(Affine<F>)) * 6 + al256(n * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
+        size_t need = al256(n * sizeof(Affine<F>)) * 2 + al256(n * sizeof(Fr)) + 17 * al256(n * sizeof(XYZZ<F>)) +
                       al256(n * sizeof(F)) + 8192;
         HK_TRY(L->reserve(need));
         const void *pd, *sd;
@@ -805,11 +806,11 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
         HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sd));
         XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
         F* pref = L->alloc_n<F>(n);
-        Affine<F>* img = L->alloc_n<Affine<F>>(4 * n);          // endomorphism images (2 used for G1, 4 for G2)
+        XYZZ<F>* tab = L->alloc_n<XYZZ<F>>(16 * n);             // subset sums of the endomorphism images (4 used in G1)
         bool out_dev = is_device_ptr(out);
         Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
-        if (!xy || !pref || !od || !img) return HK_ERR_NOMEM;
-        HK_TRY(MsmRun<F>::scalar_mul_each(L->stream, (const Affine<F>*)pd, sd, (u32)n, xy, pref, od, img));
+        if (!xy || !pref || !od || !tab) return HK_ERR_NOMEM;
+        HK_TRY(MsmRun<F>::scalar_mul_each(L->stream, (const Affine<F>*)pd, sd, (u32)n, xy, pref, od, tab));
         if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
         HK_HIP(hipStreamSynchronize(L->stream));
         return HK_OK;
@@ -856,45 +857,45 @@ hk_status Ops<C>::points_lincomb(hk_ctx* ctx, int group, const void* const* vecs
 // four ~64-bit parts on the host (c = sum +-coeffs4[j] lambda^j mod r, lambda = psi's eigenvalue), so the shared doubling
 // chain of the element-wise combination is ~66 steps instead of 254
 template <class C>
-hk_status Ops<C>::points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4, unsigned neg_mask,
-                                 size_t n, void* out) {
-    typedef typename Fq::Params P;
-    typedef Fq2 F;
+template <class F>
+hk_status Ops<C>::points_fold(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs, unsigned neg_mask, size_t n,
+                              void* out) {
+    constexpr int K = EndoOf<F>::K;
     if (n == 0) return HK_OK;
-    if (!lo || !hi || !coeffs4 || !out || n >= (1u << 28) || neg_mask > 15) return HK_ERR_ARG;
+    if (!lo || !hi || !coeffs || !out || n >= (1u << 28) || neg_mask >= (1u << K)) return HK_ERR_ARG;
     LaneGuard g(ctx);
     Lane* L = g.lane;
     if (!L) return HK_ERR_DEVICE;
-    size_t need = 7 * al256(n * sizeof(Affine<F>)) + al256(5 * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) + al256(n * sizeof(F)) + 8192;
+    size_t need = 3 * al256(n * sizeof(Affine<F>)) + al256(K * sizeof(Fr)) + ((size_t)(1 << K) + 1) * al256(n * sizeof(XYZZ<F>)) +
+                  al256(n * sizeof(F)) + 8192;
     HK_TRY(L->reserve(need));
     const void *lod, *hid;
     HK_TRY(to_device(L, lo, n * sizeof(Affine<F>), &lod));
     HK_TRY(to_device(L, hi, n * sizeof(Affine<F>), &hid));
-    Affine<F>* t[4];
-    for (auto& x : t) { x = L->alloc_n<Affine<F>>(n); if (!x) return HK_ERR_NOMEM; }
-    HK_TRY(PairRun<P>::psi4(L->stream, (const Affine<F>*)hid, (u32)n, neg_mask, t));
-    // coefficients: 1 for lo, then the four small magnitudes
-    Fr* cd = L->alloc_n<Fr>(5);
+    Fr* cd = L->alloc_n<Fr>(K);
     if (!cd) return HK_ERR_NOMEM;
-    Fr one = Fr::one();
-    if (is_device_ptr(coeffs4)) {
-        HK_HIP(hipMemcpyAsync(cd + 1, coeffs4, 4 * sizeof(Fr), hipMemcpyDeviceToDevice, L->stream));
-    } else {
-        HK_HIP(hipMemcpyAsync(cd + 1, coeffs4, 4 * sizeof(Fr), hipMemcpyHostToDevice, L->stream));
-        HK_HIP(hipStreamSynchronize(L->stream));          // the caller's buffer is pageable: done with it before returning
-    }
-    HK_HIP(hipMemcpyAsync(cd, &one, sizeof(Fr), hipMemcpyHostToDevice, L->stream));
-    HK_HIP(hipStreamSynchronize(L->stream));              // `one` lives on this stack frame
-    const Affine<F>* dv[LINCOMB_MAX] = {(const Affine<F>*)lod, t[0], t[1], t[2], t[3]};
+    HK_HIP(hipMemcpyAsync(cd, coeffs, K * sizeof(Fr), is_device_ptr(coeffs) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          L->stream));
+    if (!is_device_ptr(coeffs)) HK_HIP(hipStreamSynchronize(L->stream));      // a pageable caller buffer: done with it now
+    XYZZ<F>* tab = L->alloc_n<XYZZ<F>>(((size_t)1 << K) * n);
     XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
     F* pref = L->alloc_n<F>(n);
     bool out_dev = is_device_ptr(out);
     Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
-    if (!xy || !pref || !od) return HK_ERR_NOMEM;
-    HK_TRY(MsmRun<F>::lincomb(L->stream, dv, cd, 5u, (u32)n, xy, pref, od));
+    if (!tab || !xy || !pref || !od) return HK_ERR_NOMEM;
+    HK_TRY(MsmRun<F>::fold_endo(L->stream, (const Affine<F>*)lod, (const Affine<F>*)hid, cd, neg_mask, (u32)n, tab, xy, pref, od));
     if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
     HK_HIP(hipStreamSynchronize(L->stream));
     return HK_OK;
+}
+
+// out[i] = lo[i] + sum_{j<4} (+-) coeffs4[j] * psi^j(hi[i]) in G2: the fold lo + c * hi of a TIPA round with c split into
+// four ~64-bit parts on the host (c = sum +-coeffs4[j] lambda^j mod r, lambda = psi's eigenvalue), so the shared doubling
+// chain of the element-wise combination is ~66 steps instead of 254; one table add per step (endo.cuh)
+template <class C>
+hk_status Ops<C>::points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4, unsigned neg_mask,
+                                 size_t n, void* out) {
+    return points_fold<Fq2>(ctx, lo, hi, coeffs4, neg_mask, n, out);
 }
 
 // out[i] = lo[i] + (+-) coeffs2[0] * hi[i] + (+-) coeffs2[1] * phi(hi[i]) in G1: the G1 fold lo + c * hi with c split along the
@@ -902,37 +903,7 @@ hk_status Ops<C>::points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, co
 template <class C>
 hk_status Ops<C>::points_fold_g1(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs2, unsigned neg_mask,
                                  size_t n, void* out) {
-    typedef typename Fq::Params P;
-    typedef Fq F;
-    if (n == 0) return HK_OK;
-    if (!lo || !hi || !coeffs2 || !out || n >= (1u << 28) || neg_mask > 3) return HK_ERR_ARG;
-    LaneGuard g(ctx);
-    Lane* L = g.lane;
-    if (!L) return HK_ERR_DEVICE;
-    size_t need = 5 * al256(n * sizeof(Affine<F>)) + al256(3 * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) + al256(n * sizeof(F)) + 8192;
-    HK_TRY(L->reserve(need));
-    const void *lod, *hid;
-    HK_TRY(to_device(L, lo, n * sizeof(Affine<F>), &lod));
-    HK_TRY(to_device(L, hi, n * sizeof(Affine<F>), &hid));
-    Affine<F>* t[2];
-    for (auto& x : t) { x = L->alloc_n<Affine<F>>(n); if (!x) return HK_ERR_NOMEM; }
-    HK_TRY(PairRun<P>::phi2(L->stream, (const Affine<F>*)hid, (u32)n, neg_mask, t));
-    Fr* cd = L->alloc_n<Fr>(3);
-    if (!cd) return HK_ERR_NOMEM;
-    Fr one = Fr::one();
-    HK_HIP(hipMemcpyAsync(cd + 1, coeffs2, 2 * sizeof(Fr), is_device_ptr(coeffs2) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, L->stream));
-    HK_HIP(hipMemcpyAsync(cd, &one, sizeof(Fr), hipMemcpyHostToDevice, L->stream));
-    HK_HIP(hipStreamSynchronize(L->stream));              // `one` and a pageable coeffs2 are done with before returning
-    const Affine<F>* dv[LINCOMB_MAX] = {(const Affine<F>*)lod, t[0], t[1]};
-    XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
-    F* pref = L->alloc_n<F>(n);
-    bool out_dev = is_device_ptr(out);
-    Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
-    if (!xy || !pref || !od) return HK_ERR_NOMEM;
-    HK_TRY(MsmRun<F>::lincomb(L->stream, dv, cd, 3u, (u32)n, xy, pref, od));
-    if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
-    HK_HIP(hipStreamSynchronize(L->stream));
-    return HK_OK;
+    return points_fold<Fq>(ctx, lo, hi, coeffs2, neg_mask, n, out);
 }
 
 // z[i] = bits[i] ? 1 : 0 (Montgomery), then z[full_cols[k]] = full_vals[k]
