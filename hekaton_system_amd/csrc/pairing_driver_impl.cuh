@@ -64,7 +64,7 @@ template <class P>
 size_t PairRun<P>::scratch_bytes(u32 n, u32 count) {
     PairSteps st = pair_steps(PairLoopOf<P>::get(), TowerParams<P>::TWIST_IS_D);
     size_t S = (size_t)st.n, g0 = (n + 15) / 16;
-    size_t lines = ((size_t)count * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;
+    size_t lines = ((size_t)count * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;   // >= the n_r * S * n raw lines
     size_t pipeline = lines + 2 * count * S * g0 * sizeof(Fp12<P>);
     size_t serial = (size_t)n * count * sizeof(Fp12<P>);
     return (pipeline > serial ? pipeline : serial) + 4096;
@@ -95,15 +95,14 @@ hk_status PairRun<P>::run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<F
         u32 S = (u32)st.n;
         Line6<P>* lines = reinterpret_cast<Line6<P>*>(miller);
         // buffers behind the lines: two ping-pong arrays of at most count * S * ceil(n / 16) Fq12
-        size_t lines_bytes = ((size_t)count * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;
+        size_t lines_bytes = ((size_t)n_r * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;
         u32 g0 = (n + 15) / 16;
         Fp12<P>* pp[2];
         pp[0] = reinterpret_cast<Fp12<P>*>(reinterpret_cast<char*>(miller) + lines_bytes);
         pp[1] = pp[0] + (size_t)count * S * g0;
-        hipLaunchKernelGGL((k_pair_lines<P>), dim3((u32)(((size_t)n * n_r + 63) / 64)), dim3(64), 0, s, g1, g2, n, n_l, n_r,
-                           loop, S, lines);
+        hipLaunchKernelGGL((k_pair_lines<P>), dim3((n + 63) / 64, n_r), dim3(64), 0, s, g2, n, n_r, loop, S, lines);
         HK_DBG(s, "k_pair_lines");
-        hipLaunchKernelGGL((k_pair_tree_lines<P>), dim3(g0, count * S), dim3(64), lds_tree, s, (const Line6<P>*)lines, n, 16u, pp[0]);
+        hipLaunchKernelGGL((k_pair_tree_lines<P>), dim3(g0, count * S), dim3(64), lds_tree, s, (const Line6<P>*)lines, g1, n, 16u, n_r, S, pp[0]);
         HK_DBG(s, "k_pair_tree_lines");
         u32 m = g0;
         int cur = 0;

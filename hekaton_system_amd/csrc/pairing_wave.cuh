@@ -280,8 +280,9 @@ constexpr int WV_FINISH_SLOTS = 12;
 // ---- the Miller loop as a pipeline -------------------------------------------------------------------------------
 // prod_i f_i with f_i = Miller(P_i, Q_i) is regrouped by loop step: f = prod_s L_s^(2^(squarings after s)),
 // L_s = prod_i line_{i,s}(P_i).  (1) k_pair_lines: one lane per G2 point walks ark's projective steps ONCE and writes
-// every line, evaluated at each lhs vector's G1 point (the step arithmetic is shared by all lhs vectors);
-// (2) k_pair_tree_lines / k_pair_tree: L_s by product trees on the wave multiplier, all steps and products in parallel;
+// every line's coefficients (the step arithmetic is shared by all lhs vectors);
+// (2) k_pair_tree_lines / k_pair_tree: the lines evaluated at each lhs vector's G1 points, then L_s by product trees on the
+// wave multiplier, all steps and products in parallel;
 // (3) k_pair_horner: one wave per product folds the L_s with the loop's squarings and runs the final exponentiation.
 struct PairSteps {
     int n;                       // number of line steps S
@@ -300,16 +301,17 @@ inline PairSteps pair_steps(const PairLoop& loop, bool is_bn) {
 
 template <class P> struct Line6 { Fp2<P> c0, c1, c2; };
 
-// lines[((a * n_r + b) * S + s) * n + i]
+// RAW lines (the step's coefficients, not yet evaluated at a G1 point): lines[(b * S + s) * n + i]; a G2 point at infinity
+// writes all-zero coefficients (no real step does: its c0 / c2 carries 2yz resp. lambda, non-zero on the prime-order
+// subgroup), which the tree kernel reads as "this pair contributes 1".  The evaluation at the lhs points (4 Fq products per
+// line and lhs vector) is NOT part of this serial chain: with four lhs vectors it was 40 % of it.
 template <class P>
 __global__ void __launch_bounds__(64)
-k_pair_lines(const Affine<Fp<P>>* __restrict__ g1, const Affine<Fp2<P>>* __restrict__ g2, u32 n, u32 n_l, u32 n_r,
-             PairLoop loop, u32 S, Line6<P>* __restrict__ lines) {
+k_pair_lines(const Affine<Fp2<P>>* __restrict__ g2, u32 n, u32 n_r, PairLoop loop, u32 S, Line6<P>* __restrict__ lines) {
     typedef TowerParams<P> T;
     typedef Fp2<P> F;
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * n_r) return;
-    u32 i = (u32)(t % n), b = (u32)(t / n);
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;           // grid: (ceil(n / 64), n_r)
+    if (i >= n) return;
     Affine<F> q = ld_vec(&g2[(size_t)b * n + i]);
     bool q_inf = q.is_inf();
     G2Proj<P> r;
@@ -324,18 +326,11 @@ k_pair_lines(const Affine<Fp<P>>* __restrict__ g1, const Affine<Fp2<P>>* __restr
     }
     u32 s = 0;
     auto emit = [&](const LineCoeffs<P>& l) {
-        HK_NOUNROLL for (u32 a = 0; a < n_l; a++) {
-            Affine<Fp<P>> p = ld_vec(&g1[(size_t)a * n + i]);
-            Line6<P> o;
-            if (q_inf || p.is_inf()) { o.c0 = F::one(); o.c1 = F::zero(); o.c2 = F::zero(); }
-            else if (T::TWIST_IS_D) { o.c0 = f2_scale(l.c0, p.y); o.c1 = f2_scale(l.c1, p.x); o.c2 = l.c2; }
-            else { o.c0 = l.c0; o.c1 = f2_scale(l.c1, p.x); o.c2 = f2_scale(l.c2, p.y); }
-            Line6<P>* dst = &lines[(((size_t)a * n_r + b) * S + s) * n + i];
-            st_vec(&dst->c0, o.c0); st_vec(&dst->c1, o.c1); st_vec(&dst->c2, o.c2);
-        }
+        Line6<P>* dst = &lines[((size_t)b * S + s) * n + i];
+        st_vec(&dst->c0, l.c0); st_vec(&dst->c1, l.c1); st_vec(&dst->c2, l.c2);
         s++;
     };
-    LineCoeffs<P> dummy; dummy.c0 = F::one(); dummy.c1 = F::zero(); dummy.c2 = F::zero();
+    LineCoeffs<P> dummy; dummy.c0 = F::zero(); dummy.c1 = F::zero(); dummy.c2 = F::zero();
     HK_NOUNROLL for (int k = loop.len - 1; k >= 1; k--) {
         emit(q_inf ? dummy : pair_doubling_step(r));
         int d = loop.digits[k - 1];
@@ -348,10 +343,13 @@ k_pair_lines(const Affine<Fp<P>>* __restrict__ g1, const Affine<Fp2<P>>* __restr
     }
 }
 
-// first tree level over SPARSE lines: wave g of group y multiplies lines[y][g*c .. ) into one full Fq12
+// first tree level over SPARSE lines: wave g of group y = (a * n_r + b) * S + s evaluates the raw lines (b, s, g*c ..) at
+// the points of lhs vector a - the lanes that hold a scaled coefficient multiply it by the point's x or y, side by side -
+// and multiplies them into one full Fq12
 template <class P>
 __global__ void __launch_bounds__(64)
-k_pair_tree_lines(const Line6<P>* __restrict__ lines, u32 n, u32 c, Fp12<P>* __restrict__ out) {
+k_pair_tree_lines(const Line6<P>* __restrict__ lines, const Affine<Fp<P>>* __restrict__ g1, u32 n, u32 c, u32 n_r, u32 S,
+                  Fp12<P>* __restrict__ out) {
     extern __shared__ unsigned char pair_lds[];
     typedef WaveF12<P> W;
     typedef Fp<P> Fq;
@@ -361,26 +359,37 @@ k_pair_tree_lines(const Line6<P>* __restrict__ lines, u32 n, u32 c, Fp12<P>* __r
     WaveF12<P>::init(w);
     Fq *acc = s, *cur = s + WV_SLOT;
     u32 lo = blockIdx.x * c, hi = min(lo + c, n);
-    const Line6<P>* src = lines + (size_t)blockIdx.y * n;
+    u32 a = blockIdx.y / (n_r * S), bs = blockIdx.y % (n_r * S);
+    const Line6<P>* src = lines + (size_t)bs * n;
+    const Affine<Fq>* pts = g1 + (size_t)a * n;
     u32 lane = threadIdx.x;
     // sparse positions (ark mul_by_034 / mul_by_014): D: c0 -> 0,1  c1 -> 6,7  c2 -> 8,9;  M: c0 -> 0,1  c1 -> 2,3  c2 -> 8,9
-    auto load_line = [&](Fq* dst, const Line6<P>* l) {
-        if (lane < 13) {
-            Fq v = Fq::zero();
-            const Fq* f = reinterpret_cast<const Fq*>(l);
-            int src_idx = -1;
-            if (lane < 2) src_idx = lane;
-            else if (T::TWIST_IS_D && lane >= 6 && lane < 8) src_idx = 2 + (lane - 6);
-            else if (!T::TWIST_IS_D && lane >= 2 && lane < 4) src_idx = 2 + (lane - 2);
-            else if (lane >= 8 && lane < 10) src_idx = 4 + (lane - 8);
-            if (src_idx >= 0) v = ld_vec(&f[src_idx]);
-            dst[lane] = v;
+    // evaluation (ark `ell`): D: c0 * p.y, c1 * p.x;  M: c1 * p.x, c2 * p.y
+    int src_idx = -1, scale = 0;                    // scale: 0 none, 1 by p.x, 2 by p.y
+    if (lane < 2) { src_idx = lane; scale = T::TWIST_IS_D ? 2 : 0; }
+    else if (T::TWIST_IS_D && lane >= 6 && lane < 8) { src_idx = 2 + (lane - 6); scale = 1; }
+    else if (!T::TWIST_IS_D && lane >= 2 && lane < 4) { src_idx = 2 + (lane - 2); scale = 1; }
+    else if (lane >= 8 && lane < 10) { src_idx = 4 + (lane - 8); scale = T::TWIST_IS_D ? 0 : 2; }
+    auto load_line = [&](Fq* dst, u32 i) {
+        Fq v = Fq::zero();
+        bool raw_nz = false, pt_nz = false;
+        if (src_idx >= 0) {
+            v = ld_vec(&reinterpret_cast<const Fq*>(&src[i])[src_idx]);
+            raw_nz = !v.is_zero();
+            if (scale) {
+                Fq k = ld_vec(scale == 1 ? &pts[i].x : &pts[i].y);
+                pt_nz = !k.is_zero();
+                v = Fq::mul(v, k);
+            }
         }
+        // the pair contributes 1 when either point is at infinity (all-zero raw line / (0, 0) lhs point)
+        bool one = __ballot(raw_nz) == 0 || __ballot(pt_nz) == 0;
+        if (lane < 13) dst[lane] = one ? (lane == 0 ? Fq::one() : Fq::zero()) : v;
         W::sync();
     };
-    load_line(acc, &src[lo]);
+    load_line(acc, lo);
     for (u32 i = lo + 1; i < hi; i++) {
-        load_line(cur, &src[i]);
+        load_line(cur, i);
         W::mul(acc, acc, cur, w);
     }
     W::store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);

@@ -23,6 +23,7 @@ GPU work per round: 10 multi-pairings of n/2 pairs (two hk_pairing_products call
 (hk_points_lincomb); at the end four MSMs over the resident SRS (hk_msm_bases).
 """
 import hashlib
+import time
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 
@@ -184,6 +185,7 @@ class Tipp:
         tr = Transcript(r)
         tr.absorb(b"instance", F.encode(com.t), F.encode(com.u), F.encode(z_ab), twist.to_bytes(32, "little"), n.to_bytes(8, "little"))
         rounds, challenges = [], []
+        self.round_times = []                                               # (m, pairings s, host s, folds s) per round
         m, pos = n, 0                                                       # the current vectors start at element `pos`
         while m > 1:
             h = m // 2
@@ -193,9 +195,11 @@ class Tipp:
             v1L, v1R, v2L, v2R = L(2), R(2), L(3), R(3)
             w1L, w1R, w2L, w2R = L(4), R(4), L(5), R(5)
             # all ten multi-pairings of the round in two batched calls, issued together
+            t0 = time.perf_counter()
             fa = go(ctx.pairing_products, [aR, aL], [v1L, v2L, bL, v1R, v2R, bR], h)
             fw = go(ctx.pairing_products, [w1R, w2R, w1L, w2L], [bL, bR], h)
             pa, pw = fa.result(), fw.result()
+            t1 = time.perf_counter()
             D = F.decode
             TL = F.mul(D(pa[0, 0]), D(pw[0, 0])); UL = F.mul(D(pa[0, 1]), D(pw[1, 0])); ZL = D(pa[0, 2])
             TR = F.mul(D(pa[1, 3]), D(pw[2, 1])); UR = F.mul(D(pa[1, 4]), D(pw[3, 1])); ZR = D(pa[1, 5])
@@ -205,11 +209,13 @@ class Tipp:
             rounds.append(dict(TL=TL, UL=UL, ZL=ZL, TR=TR, UR=UR, ZR=ZR))
             challenges.append(c)
             nxt = pos + m                                                   # the folds go right behind the current vectors
+            t2 = time.perf_counter()
             folds = [go(self._fold, g, lo, hi, cc, h, win(k, nxt, h)) for k, (g, lo, hi, cc) in enumerate((
                 (1, aL, aR, c), (2, bL, bR, c_inv), (2, v1L, v1R, c_inv), (2, v2L, v2R, c_inv),
                 (1, w1L, w1R, c), (1, w2L, w2R, c)))]
             for f in folds:
                 f.result()
+            self.round_times.append((m, t1 - t0, t2 - t1, time.perf_counter() - t2))
             m, pos = h, nxt
         a, b, v1, v2, w1, w2 = (win(k, pos, 1).to_host() for k in range(6))
         arena.free()

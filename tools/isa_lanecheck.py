@@ -18,6 +18,11 @@ of an if directly under P are covered.  It is REPORTED when it is not covered an
 below P - the read is at the join, the writes are in arms.  (A read in a sibling region - `if (c) x = ..; if (c) use(x)`
 - is not reported: lane sets of sibling regions cannot be compared here.)
 
+Known benign hit (round 3, k_pair_lines with a 64-bit `t % n`): the expansion of a 64-bit division joins a 32-bit fast path
+and a 64-bit slow path and then runs `v_mad_u64_u32 v[6:7], .., v[6:7]` for a result of which only the LOW register is
+used - the high input is written in one arm only and does not matter.  The check cannot see that the high result is dead;
+the kernel got a 2-D grid instead of the division.
+
     python tools/isa_lanecheck.py [libhekaton.so | file.s-disassembly ...] [--all] [-v]
 
 Exit status 1 when anything is reported.  `make` runs it through tools/kernel_meta.py --check.
