@@ -191,6 +191,189 @@ k_points_fold_endo(const Affine<F>* __restrict__ lo, const Affine<F>* __restrict
     }
     st_vec(&out[i], ec_madd_ni(acc, l));
 }
+// ---- K lanes per element ------------------------------------------------------------------------------------------------
+// A sweep over a few hundred elements is ONE wave per SIMD at most: its time is the length of one lane's dependent chain,
+// and a chain of 68 / 131 x (double + add) cannot be shortened on one lane.  So for short vectors (n K <= SPLIT_MAX_LANES)
+// the K sub-scalars of an element go to K neighbouring lanes: lane j multiplies endo^j(P) by |k_j| alone, which lets it use
+// a 4-bit signed window (table 1P .. 8P of its own image: 4 doublings + 3 mixed adds; then one add per FOUR doublings
+// instead of one per doubling) and Jacobian coordinates (a doubling is 2M + 5S instead of XYZZ's 6M + 3S - the chain is
+// four fifths doublings now).  Per lane, in base-field products for G2: 151 (table) + 18 x (4 x 16 + 43) against
+// 68 x (24 + 40) + 440 on one lane; the K partial products meet in LDS.  Total work per element is HIGHER (K tables), so
+// long vectors keep the one-lane kernels above.
+template <class F>
+struct Jac {
+    F x, y, z;                                   // (X / Z^2, Y / Z^3); Z = 0: infinity
+    HK_HD bool is_inf() const { return z.is_zero(); }
+    HK_HD static Jac inf() { Jac r; r.x = F::one(); r.y = F::one(); r.z = F::zero(); return r; }
+    HK_HD static Jac from_affine(const Affine<F>& p) {
+        if (p.is_inf()) return inf();
+        Jac r; r.x = p.x; r.y = p.y; r.z = F::one();
+        return r;
+    }
+};
+
+// "dbl-2009-l" (a = 0): 2M + 5S; infinity maps to infinity (Z3 = 2 Y Z)
+template <class F>
+HK_RARE Jac<F> jac_dbl_ni(const Jac<F>& p) {
+    F a = F::sqr(p.x), b = F::sqr(p.y), c = F::sqr(b);
+    F d = F::dbl(F::sub(F::sub(F::sqr(F::add(p.x, b)), a), c));
+    F e = F::add(F::dbl(a), a);
+    Jac<F> r;
+    r.x = F::sub(F::sqr(e), F::dbl(d));
+    F c8 = F::dbl(F::dbl(F::dbl(c)));
+    r.y = F::sub(F::mul(e, F::sub(d, r.x)), c8);
+    r.z = F::dbl(F::mul(p.y, p.z));
+    return r;
+}
+
+// "add-2007-bl", all exceptional cases handled
+template <class F>
+HK_RARE Jac<F> jac_add_ni(const Jac<F>& p, const Jac<F>& q) {
+    if (q.is_inf()) return p;
+    if (p.is_inf()) return q;
+    F z1z1 = F::sqr(p.z), z2z2 = F::sqr(q.z);
+    F u1 = F::mul(p.x, z2z2), u2 = F::mul(q.x, z1z1);
+    F s1 = F::mul(F::mul(p.y, q.z), z2z2), s2 = F::mul(F::mul(q.y, p.z), z1z1);
+    F h = F::sub(u2, u1), rr = F::sub(s2, s1);
+    if (h.is_zero()) {
+        if (rr.is_zero()) return jac_dbl_ni(p);
+        return Jac<F>::inf();
+    }
+    rr = F::dbl(rr);
+    F i = F::sqr(F::dbl(h));
+    F j = F::mul(h, i);
+    F v = F::mul(u1, i);
+    Jac<F> r;
+    r.x = F::sub(F::sub(F::sqr(rr), j), F::dbl(v));
+    r.y = F::sub(F::mul(rr, F::sub(v, r.x)), F::dbl(F::mul(s1, j)));
+    r.z = F::mul(F::sub(F::sub(F::sqr(F::add(p.z, q.z)), z1z1), z2z2), h);
+    return r;
+}
+
+// "madd-2007-bl" with an affine, non-infinity q; all exceptional cases handled
+template <class F>
+HK_RARE Jac<F> jac_madd_ni(const Jac<F>& p, const Affine<F>& q) {
+    if (p.is_inf()) return Jac<F>::from_affine(q);
+    F z1z1 = F::sqr(p.z);
+    F u2 = F::mul(q.x, z1z1);
+    F s2 = F::mul(F::mul(q.y, p.z), z1z1);
+    F h = F::sub(u2, p.x), rr = F::sub(s2, p.y);
+    if (h.is_zero()) {
+        if (rr.is_zero()) return jac_dbl_ni(p);
+        return Jac<F>::inf();
+    }
+    rr = F::dbl(rr);
+    F hh = F::sqr(h);
+    F i = F::dbl(F::dbl(hh));
+    F j = F::mul(h, i);
+    F v = F::mul(p.x, i);
+    Jac<F> r;
+    r.x = F::sub(F::sub(F::sqr(rr), j), F::dbl(v));
+    r.y = F::sub(F::mul(rr, F::sub(v, r.x)), F::dbl(F::mul(p.y, j)));
+    r.z = F::sub(F::sub(F::sqr(F::add(p.z, h)), z1z1), hh);
+    return r;
+}
+
+constexpr u32 SPLIT_MAX_LANES = 65536;           // n K up to one wave on every SIMD of the chip
+constexpr int SPLIT_TABLE = 8;                   // 1P .. 8P
+
+// bytes of the table scratch of k_points_mul_split for n elements
+template <class F> inline size_t split_tab_bytes(size_t n) { return (size_t)SPLIT_TABLE * EndoOf<F>::K * n * sizeof(Jac<F>); }
+// bytes of the table scratch either form (one lane / K lanes per element) may ask for
+template <class F> inline size_t endo_tab_bytes(size_t n) {
+    size_t one = ((size_t)1 << EndoOf<F>::K) * n * sizeof(XYZZ<F>);
+    size_t split = n * EndoOf<F>::K <= SPLIT_MAX_LANES ? split_tab_bytes<F>(n) : 0;
+    return (one > split ? one : split) + 256;
+}
+
+// out[i] = (lo ? lo[i] : 0) + s_i * pts[i].   UNIFORM: one scalar for the whole vector, split on the host: `scalars` = K
+// Montgomery magnitudes, neg_all = their sign mask (the fold of a TIPA round);  else scalars[i], split here by every lane
+// of the element (the split is ~300 integer products: cheaper than passing it between lanes).
+// Signed 4-bit digits without a carry chain at run time: with m' = |k_j| + 0x88..8, digit d = nibble_d(m') - 8 in -8 .. 7.
+// grid: ceil(n K / 64) blocks of 64 lanes; lane t: element t / K, part t % K.   tab: split_tab_bytes(n).
+template <class Fr, class F, bool UNIFORM>
+__global__ void __launch_bounds__(64)
+k_points_mul_split(const Affine<F>* __restrict__ lo, const Affine<F>* __restrict__ pts, const Fr* __restrict__ scalars,
+                   u32 neg_all, u32 n, EndoSplit<EndoOf<F>::K> E, Jac<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
+    constexpr int K = EndoOf<F>::K;
+    constexpr int ND = (EndoOf<F>::STEPS + 3) / 4 + 1;          // nibbles of m'
+    __shared__ Jac<F> sh[64];
+    u32 t = blockIdx.x * 64 + threadIdx.x;
+    u32 i = t / K, j = t % K;
+    bool valid = i < n;
+    size_t lanes = (size_t)n * K;
+    Jac<F> acc = Jac<F>::inf();
+    if (valid) {
+        u32 m[6];
+        bool negate;
+        if (UNIFORM) {
+            Fr c = Fr::from_mont(ld_vec(&scalars[j]));
+            HK_UNROLL for (int l = 0; l < 6; l++) m[l] = c.v[l];
+            negate = (neg_all >> j) & 1u;
+        } else {
+            Fr s = Fr::from_mont(ld_vec(&scalars[i]));
+            u32 c[8];
+            HK_UNROLL for (int l = 0; l < 8; l++) c[l] = s.v[l];
+            u32 mag[K][6];
+            u32 neg = endo_decompose<K>(c, E, mag);
+            HK_UNROLL for (int l = 0; l < 6; l++) {
+                u32 v = 0;
+                HK_UNROLL for (int k = 0; k < K; k++) v = j == (u32)k ? mag[k][l] : v;
+                m[l] = v;
+            }
+            negate = (neg >> j) & 1u;
+        }
+        // m' = m + 0x88..8 over ND nibbles
+        u64 carry = 0;
+        HK_UNROLL for (int l = 0; l < 6; l++) {
+            int nib = ND - 8 * l;                                // nibbles of the bias inside limb l
+            u32 bias = nib >= 8 ? 0x88888888u : nib <= 0 ? 0u : (0x88888888u & ((1u << (4 * nib)) - 1u));
+            carry += (u64)m[l] + bias;
+            m[l] = (u32)carry;
+            carry >>= 32;
+        }
+        Affine<F> q = ld_vec(&pts[i]);
+        if (!q.is_inf()) {
+            HK_NOUNROLL for (u32 k = 0; k < j; k++) q = EndoOf<F>::apply(q);
+            if (negate) q.y = F::neg(q.y);
+            // 1P .. 8P: 2 = dbl 1, 3 = 2 + P, 4 = dbl 2, 5 = 4 + P, 6 = dbl 3, 7 = 6 + P, 8 = dbl 4
+            Jac<F> e = Jac<F>::from_affine(q);
+            st_vec(&tab[0 * lanes + t], e);
+            HK_NOUNROLL for (int k = 2; k <= SPLIT_TABLE; k++) {
+                if (k & 1) e = jac_madd_ni(ld_vec(&tab[(size_t)(k - 2) * lanes + t]), q);
+                else e = jac_dbl_ni(ld_vec(&tab[(size_t)(k / 2 - 1) * lanes + t]));
+                st_vec(&tab[(size_t)(k - 1) * lanes + t], e);
+            }
+        }
+        bool q_inf = q.is_inf();
+        HK_NOUNROLL for (int d = ND - 1; d >= 0; d--) {
+            int dig = (int)((m[d >> 3] >> (4 * (d & 7))) & 15u) - 8;
+            bool idle = q_inf || (dig == 0 && acc.is_inf());
+            if (__all(idle)) continue;                           // leading zero digits of the whole wave
+            HK_NOUNROLL for (int r = 0; r < 4; r++) acc = jac_dbl_ni(acc);
+            if (dig != 0 && !q_inf) {
+                u32 a = dig < 0 ? (u32)(-dig) : (u32)dig;
+                Jac<F> e = ld_vec(&tab[(size_t)(a - 1) * lanes + t]);
+                if (dig < 0) e.y = F::neg(e.y);
+                acc = jac_add_ni(acc, e);
+            }
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (valid && j == 0) {
+        HK_NOUNROLL for (int k = 1; k < K; k++) acc = jac_add_ni(acc, sh[threadIdx.x + k]);
+        XYZZ<F> o = XYZZ<F>::inf();
+        if (!acc.is_inf()) {
+            o.x = acc.x; o.y = acc.y;
+            o.zz = F::sqr(acc.z);
+            o.zzz = F::mul(o.zz, acc.z);
+        }
+        if (lo) o = ec_madd_ni(o, ld_vec(&lo[i]));
+        st_vec(&out[i], o);
+    }
+}
 #endif
+
 
 }  // namespace hk

@@ -63,7 +63,7 @@ struct MsmRun {
     static hk_status lincomb(hipStream_t s, const Affine<F>* const* vecs, const void* coeffs_mont, u32 k, u32 n,
                              XYZZ<F>* xy, F* pref, Affine<F>* out);
     // out[i] = lo[i] + c * hi[i], c given as EndoOf<F>::K magnitudes (Montgomery Fr) and a sign mask (endo.cuh
-    // k_points_fold_endo); tab: 2^K x n XYZZ scratch
+    // k_points_fold_endo / k_points_mul_split); tab: endo_tab_bytes(n) of scratch
     static hk_status fold_endo(hipStream_t s, const Affine<F>* lo, const Affine<F>* hi, const void* coeffs_mont, u32 neg_mask,
                                u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out);
     // largest private-memory ("scratch") frame per lane among this flavour's kernels, from the loaded code object

@@ -131,7 +131,7 @@ size_t MsmRun<F>::max_private_bytes() {
                         (const void*)k_msm_reduce_fused<F>, (const void*)k_msm_bucket_reduce<F>,
                         (const void*)k_msm_window_sum<F>, (const void*)k_msm_final<F>, (const void*)k_to_affine<F>,
                         (const void*)k_msm_build_tables<F>, (const void*)k_batch_affine<F>, (const void*)k_fb_table<F>,
-                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>, (const void*)k_points_fold_endo<Fr, F>,
+                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>, (const void*)k_points_fold_endo<Fr, F>, (const void*)k_points_mul_split<Fr, F, true>, (const void*)k_points_mul_split<Fr, F, false>,
                         (const void*)k_points_lincomb<Fr, F>};
     size_t m = 0;
     for (const void* k : ks) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }
@@ -170,7 +170,14 @@ hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const 
     typedef typename ScalarOf<F>::type Fr;
     if (n == 0) return HK_OK;
     static const bool plain = getenv("HK_SCALAR_MUL_PLAIN") != nullptr;      // the 254-step ladder (A/B, debugging)
-    if (tab && !plain) {
+    const bool one_lane = getenv("HK_ENDO_ONE_LANE") != nullptr;             // never K lanes per element (A/B, tests)
+    if (tab && !plain && !one_lane && (size_t)n * EndoOf<F>::K <= SPLIT_MAX_LANES) {
+        // short vector: K lanes per element, 4-bit windows, Jacobian chain (endo.cuh)
+        static const auto E = EndoOf<F>::split();
+        u32 lanes = n * EndoOf<F>::K;
+        hipLaunchKernelGGL((k_points_mul_split<Fr, F, false>), dim3((lanes + 63) / 64), dim3(64), 0, s, (const Affine<F>*)nullptr,
+                           pts, (const Fr*)scalars_mont, 0u, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
+    } else if (tab && !plain) {
         // scalars split on the device along phi / psi: one shared chain of 131 (G1) / 68 (G2) doublings (endo.cuh)
         static const auto E = EndoOf<F>::split();
         hipLaunchKernelGGL((k_scalar_mul_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, pts, (const Fr*)scalars_mont, n, E,
@@ -188,8 +195,15 @@ hk_status MsmRun<F>::fold_endo(hipStream_t s, const Affine<F>* lo, const Affine<
                                u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out) {
     typedef typename ScalarOf<F>::type Fr;
     if (n == 0) return HK_OK;
-    hipLaunchKernelGGL((k_points_fold_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, lo, hi, (const Fr*)coeffs_mont,
-                       neg_mask, n, tab, xy);
+    const bool one_lane = getenv("HK_ENDO_ONE_LANE") != nullptr;
+    if (!one_lane && (size_t)n * EndoOf<F>::K <= SPLIT_MAX_LANES) {
+        static const auto E = EndoOf<F>::split();                                // unused by the uniform form
+        u32 lanes = n * EndoOf<F>::K;
+        hipLaunchKernelGGL((k_points_mul_split<Fr, F, true>), dim3((lanes + 63) / 64), dim3(64), 0, s, lo, hi,
+                           (const Fr*)coeffs_mont, neg_mask, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
+    } else
+        hipLaunchKernelGGL((k_points_fold_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, lo, hi, (const Fr*)coeffs_mont,
+                           neg_mask, n, tab, xy);
     HK_HIP(hipGetLastError());
     return batch_affine(s, xy, out, pref, n);
 }

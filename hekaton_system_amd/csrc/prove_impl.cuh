@@ -798,15 +798,15 @@ hk_status Ops<C>::scalar_pairing(hk_ctx* ctx, int group, const void* points, con
     if (!L) return HK_ERR_DEVICE;
     auto run = [&](auto ftag) -> hk_status {
         typedef decltype(ftag) F;
-        size_t need = al256(n * sizeof(Affine<F>)) * 2 + al256(n * sizeof(Fr)) + 17 * al256(n * sizeof(XYZZ<F>)) +
-                      al256(n * sizeof(F)) + 8192;
+        size_t need = al256(n * sizeof(Affine<F>)) * 2 + al256(n * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
+                      al256(endo_tab_bytes<F>(n)) + al256(n * sizeof(F)) + 8192;
         HK_TRY(L->reserve(need));
         const void *pd, *sd;
         HK_TRY(to_device(L, points, n * sizeof(Affine<F>), &pd));
         HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sd));
         XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
         F* pref = L->alloc_n<F>(n);
-        XYZZ<F>* tab = L->alloc_n<XYZZ<F>>(16 * n);             // subset sums of the endomorphism images (4 used in G1)
+        XYZZ<F>* tab = (XYZZ<F>*)L->alloc_n<unsigned char>(endo_tab_bytes<F>(n));   // the chains' tables (endo.cuh)
         bool out_dev = is_device_ptr(out);
         Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
         if (!xy || !pref || !od || !tab) return HK_ERR_NOMEM;
@@ -866,8 +866,8 @@ hk_status Ops<C>::points_fold(hk_ctx* ctx, const void* lo, const void* hi, const
     LaneGuard g(ctx);
     Lane* L = g.lane;
     if (!L) return HK_ERR_DEVICE;
-    size_t need = 3 * al256(n * sizeof(Affine<F>)) + al256(K * sizeof(Fr)) + ((size_t)(1 << K) + 1) * al256(n * sizeof(XYZZ<F>)) +
-                  al256(n * sizeof(F)) + 8192;
+    size_t need = 3 * al256(n * sizeof(Affine<F>)) + al256(K * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
+                  al256(endo_tab_bytes<F>(n)) + al256(n * sizeof(F)) + 8192;
     HK_TRY(L->reserve(need));
     const void *lod, *hid;
     HK_TRY(to_device(L, lo, n * sizeof(Affine<F>), &lod));
@@ -877,7 +877,7 @@ hk_status Ops<C>::points_fold(hk_ctx* ctx, const void* lo, const void* hi, const
     HK_HIP(hipMemcpyAsync(cd, coeffs, K * sizeof(Fr), is_device_ptr(coeffs) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           L->stream));
     if (!is_device_ptr(coeffs)) HK_HIP(hipStreamSynchronize(L->stream));      // a pageable caller buffer: done with it now
-    XYZZ<F>* tab = L->alloc_n<XYZZ<F>>(((size_t)1 << K) * n);
+    XYZZ<F>* tab = (XYZZ<F>*)L->alloc_n<unsigned char>(endo_tab_bytes<F>(n));
     XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
     F* pref = L->alloc_n<F>(n);
     bool out_dev = is_device_ptr(out);

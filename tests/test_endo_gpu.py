@@ -115,3 +115,37 @@ def test_scalar_pairing_over_the_endomorphism_equals_the_oracle(cname, group, ct
             continue
         want = G.mul(G.mul(gen, ks[i]), scalars[i])
         assert have == (want[0], want[1]), (cname, group, i, scalars[i])
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "bn254"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_k_lanes_per_element_equals_one_lane_per_element(cname, group, ctx_bn254, ctx_bls, monkeypatch):
+    """Short vectors run k_points_mul_split (K lanes per element, signed 4-bit windows, Jacobian chain), long ones the
+    one-lane kernels (k_scalar_mul_endo / k_points_fold_endo): the same bytes from both, for `scalar_pairing` and for the
+    fold lo + c * hi with a non-trivial lo, on a vector that is neither a multiple of the 64 / K elements of a workgroup
+    nor free of infinity points; small magnitudes (leading zero digits of every lane) included."""
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    cp, fc, cd = CURVES[cname], FrCodec(cname), Codec(CURVES[cname])
+    gen = cp.g1_gen if group == 1 else cp.g2_gen
+    pb = ctx.g1_bytes if group == 1 else ctx.g2_bytes
+    rnd = random.Random(11 + group)
+    n = 1501
+    vec = (cd.g1_vec if group == 1 else cd.g2_vec)([gen])
+    hi = ctx.fixed_base(group, vec, fc.enc([rnd.randrange(1, cp.r) for _ in range(n)])).copy()
+    lo = ctx.fixed_base(group, vec, fc.enc([rnd.randrange(1, cp.r) for _ in range(n)])).copy()
+    for i in (0, 5, 63, 64, 1500):
+        hi[i * pb:(i + 1) * pb] = 0
+    lo[5 * pb:6 * pb] = 0
+    lo[7 * pb:8 * pb] = 0
+    scalars = [rnd.randrange(cp.r) for _ in range(n)]
+    scalars[:6] = [0, 1, cp.r - 1, 7, 8, 1 << 64]
+    fold = ctx.points_fold_g1 if group == 1 else ctx.points_fold_g2
+    coeffs = [rnd.randrange(cp.r), 1, 8, cp.r - 8, 0]
+    split = [ctx.scalar_pairing(group, hi, fc.enc(scalars), n=n).copy()] + [fold(lo, hi, c, n=n).copy() for c in coeffs]
+    monkeypatch.setenv("HK_ENDO_ONE_LANE", "1")
+    one = [ctx.scalar_pairing(group, hi, fc.enc(scalars), n=n).copy()] + [fold(lo, hi, c, n=n).copy() for c in coeffs]
+    for k, (a, b) in enumerate(zip(split, one)):
+        assert np.array_equal(a, b), (cname, group, k)
+    # lo + 0 * hi = lo, lo + 1 * hi where hi = O is lo
+    assert np.array_equal(split[5], lo)
+    assert np.array_equal(split[2][5 * pb:6 * pb], np.zeros(pb, np.uint8))
