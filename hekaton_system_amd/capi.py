@@ -67,7 +67,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_poseidon_path"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_points_fold_many_g1", "hk_points_fold_many_g2", "hk_pairing_pairs", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_poseidon_path"]
 
 _lib = None
 
@@ -111,6 +111,7 @@ def load():
     if hasattr(lib, "hk_multi_pairing"):          # absent only from older experiment builds loaded through HK_LIB
         lib.hk_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
         lib.hk_pairing_products.argtypes = [vp, C.POINTER(vp), sz, C.POINTER(vp), sz, sz, vp]
+        lib.hk_pairing_pairs.argtypes = [vp, C.POINTER(vp), sz, C.POINTER(vp), sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, vp]
         lib.hk_ctx_gt_bytes.argtypes = [vp, C.POINTER(sz)]
         for f in (lib.hk_points_lincomb_g1, lib.hk_points_lincomb_g2):
             f.argtypes = [vp, C.POINTER(vp), vp, sz, sz, vp]
@@ -118,6 +119,8 @@ def load():
         lib.hk_points_fold_g2.argtypes = [vp, vp, vp, vp, C.c_uint, sz, vp]
     if hasattr(lib, "hk_points_fold_g1"):
         lib.hk_points_fold_g1.argtypes = [vp, vp, vp, vp, C.c_uint, sz, vp]
+    for name in ("hk_points_fold_many_g1", "hk_points_fold_many_g2"):
+        getattr(lib, name).argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), vp, C.c_uint, sz, C.POINTER(vp)]
     if hasattr(lib, "hk_assignment_from_bits"):
         lib.hk_assignment_from_bits.argtypes = [vp, vp, sz, vp, vp, sz, vp]
         lib.hk_wprog_upload.argtypes = [vp, vp, sz, vp, sz, vp, sz, sz, sz, C.POINTER(vp)]
@@ -313,6 +316,21 @@ class Context:
               "hk_pairing_products")
         return out
 
+    def pairing_pairs(self, lhs, rhs, pairs, n=None):
+        """pairing(lhs[a], rhs[b]) for each (a, b) of `pairs` in one batched launch (hk_pairing_pairs: the cross terms of a
+        GIPA round): returns a (len(pairs), gt_bytes) uint8 array."""
+        n = n if n is not None else len(lhs[0]) // self.g1_bytes
+        keep = [x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8) for x in list(lhs) + list(rhs)]
+        addr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data
+        lp = (C.c_void_p * len(lhs))(*[addr(x) for x in keep[:len(lhs)]])
+        rp = (C.c_void_p * len(rhs))(*[addr(x) for x in keep[len(lhs):]])
+        pa = (C.c_uint32 * len(pairs))(*[a for a, _ in pairs])
+        pb = (C.c_uint32 * len(pairs))(*[b for _, b in pairs])
+        out = np.zeros((len(pairs), self.gt_bytes), dtype=np.uint8)
+        check(self.lib.hk_pairing_pairs(self.handle, lp, len(lhs), rp, len(rhs), pa, pb, len(pairs), n, out.ctypes.data),
+              "hk_pairing_pairs")
+        return out
+
     def points_lincomb(self, group, vecs, coeffs, n=None):
         """out[i] = sum_j coeffs[j] * vecs[j][i] (aggregation.rs:192-203,293-326); coeffs: k Fr Montgomery bytes."""
         pb = self.g1_bytes if group == 1 else self.g2_bytes
@@ -357,6 +375,22 @@ class Context:
         check(self.lib.hk_points_fold_g1(self.handle, ptr(lo_), ptr(hi_), coeffs.ctypes.data, neg, n,
                                          res.ptr if isinstance(res, DeviceBuffer) else res.ctypes.data), "hk_points_fold_g1")
         return res
+
+    def points_fold_many(self, group, los, his, c, n, outs):
+        """outs[y][i] = los[y][i] + c * his[y][i] for up to 4 vector pairs and one scalar c (hk_points_fold_many_g1 / _g2):
+        the folds of one TIPA round that share a challenge.  los / his: DeviceBuffer / DeviceView or uint8 arrays; outs:
+        DeviceBuffer / DeviceView (stay in HBM) or uint8 arrays of n points each."""
+        from .cp_groth16 import FrCodec
+        from .endo import phi2, psi4
+        k = (phi2 if group == 1 else psi4)(self.curve).decompose(c)
+        neg = sum(1 << j for j, v in enumerate(k) if v < 0)
+        coeffs = np.ascontiguousarray(FrCodec(self.curve).enc([abs(v) for v in k]), dtype=np.uint8)
+        keep = [[x if isinstance(x, DeviceBuffer) else np.ascontiguousarray(x, dtype=np.uint8) for x in xs] for xs in (los, his)]
+        ptr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x.ctypes.data
+        arr = lambda xs: (C.c_void_p * len(xs))(*[ptr(x) for x in xs])
+        fn = self.lib.hk_points_fold_many_g1 if group == 1 else self.lib.hk_points_fold_many_g2
+        check(fn(self.handle, len(outs), arr(keep[0]), arr(keep[1]), coeffs.ctypes.data, neg, n, arr(outs)), fn.__name__)
+        return outs
 
     def assignment_from_bits(self, bits, full_cols, full_vals, out=None):
         """hk_assignment_from_bits: the Montgomery assignment of a bit-valued witness, materialised in HBM.  bits: uint8

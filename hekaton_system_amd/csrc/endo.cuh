@@ -280,9 +280,9 @@ constexpr int SPLIT_TABLE = 8;                   // 1P .. 8P
 // bytes of the table scratch of k_points_mul_split for n elements
 template <class F> inline size_t split_tab_bytes(size_t n) { return (size_t)SPLIT_TABLE * EndoOf<F>::K * n * sizeof(Jac<F>); }
 // bytes of the table scratch either form (one lane / K lanes per element) may ask for
-template <class F> inline size_t endo_tab_bytes(size_t n) {
+template <class F> inline size_t endo_tab_bytes(size_t n, size_t vectors = 1) {
     size_t one = ((size_t)1 << EndoOf<F>::K) * n * sizeof(XYZZ<F>);
-    size_t split = n * EndoOf<F>::K <= SPLIT_MAX_LANES ? split_tab_bytes<F>(n) : 0;
+    size_t split = n * EndoOf<F>::K <= SPLIT_MAX_LANES ? vectors * split_tab_bytes<F>(n) : 0;
     return (one > split ? one : split) + 256;
 }
 
@@ -290,18 +290,27 @@ template <class F> inline size_t endo_tab_bytes(size_t n) {
 // Montgomery magnitudes, neg_all = their sign mask (the fold of a TIPA round);  else scalars[i], split here by every lane
 // of the element (the split is ~300 integer products: cheaper than passing it between lanes).
 // Signed 4-bit digits without a carry chain at run time: with m' = |k_j| + 0x88..8, digit d = nibble_d(m') - 8 in -8 .. 7.
-// grid: ceil(n K / 64) blocks of 64 lanes; lane t: element t / K, part t % K.   tab: split_tab_bytes(n).
+// grid: (ceil(n K / 64), vectors) blocks of 64 lanes; lane t: element t / K, part t % K; vector y = blockIdx.y reads
+// v.lo[y] / v.pts[y] and writes out[y n ..) (UNIFORM: the same scalar for every vector - the folds of one TIPA round).
+// tab: vectors x split_tab_bytes(n).
+constexpr int FOLD_MAX = 4;
+template <class F> struct SplitVecs { const Affine<F>* lo[FOLD_MAX]; const Affine<F>* pts[FOLD_MAX]; };
+
 template <class Fr, class F, bool UNIFORM>
 __global__ void __launch_bounds__(64)
-k_points_mul_split(const Affine<F>* __restrict__ lo, const Affine<F>* __restrict__ pts, const Fr* __restrict__ scalars,
-                   u32 neg_all, u32 n, EndoSplit<EndoOf<F>::K> E, Jac<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
+k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, u32 n, EndoSplit<EndoOf<F>::K> E,
+                   Jac<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
     constexpr int K = EndoOf<F>::K;
     constexpr int ND = (EndoOf<F>::STEPS + 3) / 4 + 1;          // nibbles of m'
     __shared__ Jac<F> sh[64];
+    const Affine<F>* __restrict__ lo = v.lo[blockIdx.y];
+    const Affine<F>* __restrict__ pts = v.pts[blockIdx.y];
     u32 t = blockIdx.x * 64 + threadIdx.x;
     u32 i = t / K, j = t % K;
     bool valid = i < n;
     size_t lanes = (size_t)n * K;
+    tab += (size_t)blockIdx.y * SPLIT_TABLE * lanes;
+    out += (size_t)blockIdx.y * n;
     Jac<F> acc = Jac<F>::inf();
     if (valid) {
         u32 m[6];

@@ -404,6 +404,21 @@ hk_status hk_points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const v
     if (!ctx || !ctx->ops) return HK_ERR_ARG;
     return ctx->ops->points_fold_g2(ctx, lo, hi, coeffs4_mont, neg_mask, n, out);
 }
+hk_status hk_points_fold_many_g1(hk_ctx* ctx, size_t k, const void* const* lo, const void* const* hi, const void* coeffs2_mont,
+                                 unsigned neg_mask, size_t n, void* const* out) {
+    if (!ctx || !ctx->ops) return HK_ERR_ARG;
+    return ctx->ops->points_fold_many(ctx, 1, k, lo, hi, coeffs2_mont, neg_mask, n, out);
+}
+hk_status hk_points_fold_many_g2(hk_ctx* ctx, size_t k, const void* const* lo, const void* const* hi, const void* coeffs4_mont,
+                                 unsigned neg_mask, size_t n, void* const* out) {
+    if (!ctx || !ctx->ops) return HK_ERR_ARG;
+    return ctx->ops->points_fold_many(ctx, 2, k, lo, hi, coeffs4_mont, neg_mask, n, out);
+}
+hk_status hk_pairing_pairs(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2, size_t n_rhs,
+                           const uint32_t* pair_lhs, const uint32_t* pair_rhs, size_t n_pairs, size_t n, void* gt_out) {
+    if (!ctx || !lhs_g1 || !rhs_g2 || !pair_lhs || !pair_rhs || !gt_out) return HK_ERR_ARG;
+    return ctx->ops->pairing_pairs(ctx, lhs_g1, n_lhs, rhs_g2, n_rhs, pair_lhs, pair_rhs, n_pairs, n, gt_out);
+}
 hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2,
                               size_t n_rhs, size_t n, void* gt_out) {
     if (!ctx || !lhs_g1 || !rhs_g2 || !gt_out) return HK_ERR_ARG;

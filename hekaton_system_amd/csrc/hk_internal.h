@@ -132,6 +132,10 @@ struct CurveOps {
     hk_status (*poseidon_path)(hk_ctx*, const void* consts, size_t n_consts, const hk_poseidon_desc* leaf_hash,
                                const hk_poseidon_desc* node_hash, const void* leaf, const void* siblings,
                                const uint32_t* index, size_t depth, size_t batch, size_t n_v, size_t col0, void* z_out);
+    hk_status (*points_fold_many)(hk_ctx*, int group, size_t k, const void* const* lo, const void* const* hi,
+                                  const void* coeffs, unsigned neg_mask, size_t n, void* const* out);
+    hk_status (*pairing_pairs)(hk_ctx*, const void* const* lhs, size_t n_lhs, const void* const* rhs, size_t n_rhs,
+                               const uint32_t* pair_lhs, const uint32_t* pair_rhs, size_t n_pairs, size_t n, void* out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

@@ -64,21 +64,30 @@ struct MsmRun {
                              XYZZ<F>* xy, F* pref, Affine<F>* out);
     // out[i] = lo[i] + c * hi[i], c given as EndoOf<F>::K magnitudes (Montgomery Fr) and a sign mask (endo.cuh
     // k_points_fold_endo / k_points_mul_split); tab: endo_tab_bytes(n) of scratch
-    static hk_status fold_endo(hipStream_t s, const Affine<F>* lo, const Affine<F>* hi, const void* coeffs_mont, u32 neg_mask,
-                               u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out);
+    static hk_status fold_endo(hipStream_t s, u32 k, const Affine<F>* const* lo, const Affine<F>* const* hi, const void* coeffs_mont,
+                               u32 neg_mask, u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out);
     // largest private-memory ("scratch") frame per lane among this flavour's kernels, from the loaded code object
     // (hipFuncGetAttributes): what sizes a hardware queue's scratch ring
     static size_t max_private_bytes();
+};
+
+// which (lhs vector, rhs vector) pairs a call multiplies out: n = 0 -> every pair, product p = a * n_r + b; else product p
+// pairs lhs vector a[p] with rhs vector b[p] (hk_pairing_pairs: the ten cross terms of a GIPA round out of 6 x 6)
+constexpr int PAIR_LIST_MAX = 64;
+struct PairList {
+    u32 n;
+    unsigned char a[PAIR_LIST_MAX], b[PAIR_LIST_MAX];
 };
 
 // multi-pairing launch sequence (pairing.cuh); explicit instantiation in hk_<curve>_pair.hip
 template <class P>
 struct PairRun {
     // g1: n_l vectors of n points, g2: n_r vectors of n points (device).  miller: scratch_bytes(n, n_l*n_r) of scratch,
-    // prod: n_l*n_r scratch, out: n_l*n_r results (device), out[a*n_r + b] = prod_i e(g1[a][i], g2[b][i]).
+    // prod: n_l*n_r scratch, out: n_l*n_r results (device), out[a*n_r + b] = prod_i e(g1[a][i], g2[b][i]);
+    // with `pairs`: count = pairs->n products, out[p] = prod_i e(g1[pairs->a[p]][i], g2[pairs->b[p]][i]).
     static hk_status run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<Fp2<P>>* g2, u32 n, u32 n_l, u32 n_r,
-                         Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out);
-    static size_t scratch_bytes(u32 n, u32 count);
+                         Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out, const PairList* pairs = nullptr);
+    static size_t scratch_bytes(u32 n, u32 count, u32 n_r);
     static size_t max_private_bytes();   // as MsmRun<F>::max_private_bytes, over the pairing / endomorphism kernels
     static u32 steps();          // line-evaluation steps of the Miller loop (the factor of `count` in the tree launches' grid.y)
     // out[e] = in[e]^scalars[e] (GT powers; device pointers)

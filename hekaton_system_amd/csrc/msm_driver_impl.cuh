@@ -175,8 +175,10 @@ hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const 
         // short vector: K lanes per element, 4-bit windows, Jacobian chain (endo.cuh)
         static const auto E = EndoOf<F>::split();
         u32 lanes = n * EndoOf<F>::K;
-        hipLaunchKernelGGL((k_points_mul_split<Fr, F, false>), dim3((lanes + 63) / 64), dim3(64), 0, s, (const Affine<F>*)nullptr,
-                           pts, (const Fr*)scalars_mont, 0u, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
+        SplitVecs<F> v = {};
+        v.pts[0] = pts;
+        hipLaunchKernelGGL((k_points_mul_split<Fr, F, false>), dim3((lanes + 63) / 64), dim3(64), 0, s, v,
+                           (const Fr*)scalars_mont, 0u, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
     } else if (tab && !plain) {
         // scalars split on the device along phi / psi: one shared chain of 131 (G1) / 68 (G2) doublings (endo.cuh)
         static const auto E = EndoOf<F>::split();
@@ -191,21 +193,26 @@ hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const 
 }
 
 template <class F>
-hk_status MsmRun<F>::fold_endo(hipStream_t s, const Affine<F>* lo, const Affine<F>* hi, const void* coeffs_mont, u32 neg_mask,
-                               u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out) {
+hk_status MsmRun<F>::fold_endo(hipStream_t s, u32 k, const Affine<F>* const* lo, const Affine<F>* const* hi, const void* coeffs_mont,
+                               u32 neg_mask, u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out) {
     typedef typename ScalarOf<F>::type Fr;
-    if (n == 0) return HK_OK;
+    if (n == 0 || k == 0) return HK_OK;
+    if (k > (u32)FOLD_MAX) return HK_ERR_ARG;
     const bool one_lane = getenv("HK_ENDO_ONE_LANE") != nullptr;
     if (!one_lane && (size_t)n * EndoOf<F>::K <= SPLIT_MAX_LANES) {
         static const auto E = EndoOf<F>::split();                                // unused by the uniform form
         u32 lanes = n * EndoOf<F>::K;
-        hipLaunchKernelGGL((k_points_mul_split<Fr, F, true>), dim3((lanes + 63) / 64), dim3(64), 0, s, lo, hi,
+        SplitVecs<F> v = {};
+        for (u32 y = 0; y < k; y++) { v.lo[y] = lo[y]; v.pts[y] = hi[y]; }
+        hipLaunchKernelGGL((k_points_mul_split<Fr, F, true>), dim3((lanes + 63) / 64, k), dim3(64), 0, s, v,
                            (const Fr*)coeffs_mont, neg_mask, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
-    } else
-        hipLaunchKernelGGL((k_points_fold_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, lo, hi, (const Fr*)coeffs_mont,
-                           neg_mask, n, tab, xy);
+    } else {
+        for (u32 y = 0; y < k; y++)                                              // long vectors: throughput-bound, one after the other
+            hipLaunchKernelGGL((k_points_fold_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, lo[y], hi[y], (const Fr*)coeffs_mont,
+                               neg_mask, n, tab, xy + (size_t)y * n);
+    }
     HK_HIP(hipGetLastError());
-    return batch_affine(s, xy, out, pref, n);
+    return batch_affine(s, xy, out, pref, k * n);
 }
 
 template <class F>

@@ -61,10 +61,10 @@ u32 PairRun<P>::steps() {
 }
 
 template <class P>
-size_t PairRun<P>::scratch_bytes(u32 n, u32 count) {
+size_t PairRun<P>::scratch_bytes(u32 n, u32 count, u32 n_r) {
     PairSteps st = pair_steps(PairLoopOf<P>::get(), TowerParams<P>::TWIST_IS_D);
     size_t S = (size_t)st.n, g0 = (n + 15) / 16;
-    size_t lines = ((size_t)count * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;   // >= the n_r * S * n raw lines
+    size_t lines = ((size_t)n_r * S * n * sizeof(Line6<P>) + 255) & ~(size_t)255;
     size_t pipeline = lines + 2 * count * S * g0 * sizeof(Fp12<P>);
     size_t serial = (size_t)n * count * sizeof(Fp12<P>);
     return (pipeline > serial ? pipeline : serial) + 4096;
@@ -72,15 +72,22 @@ size_t PairRun<P>::scratch_bytes(u32 n, u32 count) {
 
 template <class P>
 hk_status PairRun<P>::run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<Fp2<P>>* g2, u32 n, u32 n_l, u32 n_r,
-                          Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out) {
-    u32 count = n_l * n_r;
+                          Fp12<P>* miller, Fp12<P>* prod, Fp12<P>* out, const PairList* pairs) {
+    u32 count = pairs ? pairs->n : n_l * n_r;
+    PairList pl;
+    pl.n = 0;
+    if (pairs) {
+        if (pairs->n == 0 || pairs->n > (u32)PAIR_LIST_MAX) return HK_ERR_ARG;
+        for (u32 k = 0; k < pairs->n; k++) if (pairs->a[k] >= n_l || pairs->b[k] >= n_r) return HK_ERR_ARG;
+        pl = *pairs;
+    }
     size_t total = (size_t)n * count;
     if (count == 0 || n == 0) return HK_ERR_ARG;
     PairLoop loop = PairLoopOf<P>::get();
     static const bool serial = getenv("HK_PAIR_SERIAL") != nullptr;      // one lane per pair / per product (A/B, debugging)
     size_t lds_tree = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
     size_t lds_fin = sizeof(WaveArea<P>) + WV_FINISH_SLOTS * WV_SLOT * sizeof(Fp<P>);
-    if (serial) {
+    if (serial && !pairs) {
         hipLaunchKernelGGL((k_pair_miller<P>), dim3((u32)((total + 63) / 64)), dim3(64), 0, s, g1, g2, n, n_l, n_r, loop, miller);
         HK_DBG(s, "k_pair_miller");
         hipLaunchKernelGGL((k_f12_product<P>), dim3(count), dim3(PAIR_TREE_THREADS), sizeof(Fp12<P>) * PAIR_TREE_THREADS, s,
@@ -102,7 +109,7 @@ hk_status PairRun<P>::run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<F
         pp[1] = pp[0] + (size_t)count * S * g0;
         hipLaunchKernelGGL((k_pair_lines<P>), dim3((n + 63) / 64, n_r), dim3(64), 0, s, g2, n, n_r, loop, S, lines);
         HK_DBG(s, "k_pair_lines");
-        hipLaunchKernelGGL((k_pair_tree_lines<P>), dim3(g0, count * S), dim3(64), lds_tree, s, (const Line6<P>*)lines, g1, n, 16u, n_r, S, pp[0]);
+        hipLaunchKernelGGL((k_pair_tree_lines<P>), dim3(g0, count * S), dim3(64), lds_tree, s, (const Line6<P>*)lines, g1, n, 16u, n_r, S, pl, pp[0]);
         HK_DBG(s, "k_pair_tree_lines");
         u32 m = g0;
         int cur = 0;

@@ -301,6 +301,7 @@ inline PairSteps pair_steps(const PairLoop& loop, bool is_bn) {
 
 template <class P> struct Line6 { Fp2<P> c0, c1, c2; };
 
+
 // RAW lines (the step's coefficients, not yet evaluated at a G1 point): lines[(b * S + s) * n + i]; a G2 point at infinity
 // writes all-zero coefficients (no real step does: its c0 / c2 carries 2yz resp. lambda, non-zero on the prime-order
 // subgroup), which the tree kernel reads as "this pair contributes 1".  The evaluation at the lhs points (4 Fq products per
@@ -345,11 +346,11 @@ k_pair_lines(const Affine<Fp2<P>>* __restrict__ g2, u32 n, u32 n_r, PairLoop loo
 
 // first tree level over SPARSE lines: wave g of group y = (a * n_r + b) * S + s evaluates the raw lines (b, s, g*c ..) at
 // the points of lhs vector a - the lanes that hold a scaled coefficient multiply it by the point's x or y, side by side -
-// and multiplies them into one full Fq12
+// and multiplies them into one full Fq12 (product p = blockIdx.y / S pairs lhs vector a with rhs vector b: PairList)
 template <class P>
 __global__ void __launch_bounds__(64)
 k_pair_tree_lines(const Line6<P>* __restrict__ lines, const Affine<Fp<P>>* __restrict__ g1, u32 n, u32 c, u32 n_r, u32 S,
-                  Fp12<P>* __restrict__ out) {
+                  PairList pl, Fp12<P>* __restrict__ out) {
     extern __shared__ unsigned char pair_lds[];
     typedef WaveF12<P> W;
     typedef Fp<P> Fq;
@@ -359,8 +360,9 @@ k_pair_tree_lines(const Line6<P>* __restrict__ lines, const Affine<Fp<P>>* __res
     WaveF12<P>::init(w);
     Fq *acc = s, *cur = s + WV_SLOT;
     u32 lo = blockIdx.x * c, hi = min(lo + c, n);
-    u32 a = blockIdx.y / (n_r * S), bs = blockIdx.y % (n_r * S);
-    const Line6<P>* src = lines + (size_t)bs * n;
+    u32 p = blockIdx.y / S, st = blockIdx.y % S;
+    u32 a = pl.n ? pl.a[p] : p / n_r, b = pl.n ? pl.b[p] : p % n_r;
+    const Line6<P>* src = lines + ((size_t)b * S + st) * n;
     const Affine<Fq>* pts = g1 + (size_t)a * n;
     u32 lane = threadIdx.x;
     // sparse positions (ark mul_by_034 / mul_by_014): D: c0 -> 0,1  c1 -> 6,7  c2 -> 8,9;  M: c0 -> 0,1  c1 -> 2,3  c2 -> 8,9

@@ -853,38 +853,48 @@ hk_status Ops<C>::points_lincomb(hk_ctx* ctx, int group, const void* const* vecs
     return group == 1 ? run(Fq()) : run(Fq2());
 }
 
-// out[i] = lo[i] + sum_{j<4} (+-) coeffs4[j] * psi^j(hi[i]) in G2: the fold lo + c * hi of a TIPA round with c split into
-// four ~64-bit parts on the host (c = sum +-coeffs4[j] lambda^j mod r, lambda = psi's eigenvalue), so the shared doubling
-// chain of the element-wise combination is ~66 steps instead of 254
+// out_y[i] = lo_y[i] + c * hi_y[i] for k <= FOLD_MAX vector pairs and ONE scalar c, split by the caller along the group's
+// endomorphism into K magnitudes and a sign mask (G2: four ~64-bit parts along psi, G1: two ~128-bit parts along phi): the
+// folds of one TIPA round that share a challenge go out as one launch and one normalisation
 template <class C>
 template <class F>
-hk_status Ops<C>::points_fold(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs, unsigned neg_mask, size_t n,
-                              void* out) {
+hk_status Ops<C>::points_fold(hk_ctx* ctx, size_t k, const void* const* lo, const void* const* hi, const void* coeffs,
+                              unsigned neg_mask, size_t n, void* const* out) {
     constexpr int K = EndoOf<F>::K;
-    if (n == 0) return HK_OK;
-    if (!lo || !hi || !coeffs || !out || n >= (1u << 28) || neg_mask >= (1u << K)) return HK_ERR_ARG;
+    if (n == 0 || k == 0) return HK_OK;
+    if (!lo || !hi || !coeffs || !out || k > (size_t)FOLD_MAX || n >= (1u << 28) / FOLD_MAX || neg_mask >= (1u << K)) return HK_ERR_ARG;
+    for (size_t y = 0; y < k; y++) if (!lo[y] || !hi[y] || !out[y]) return HK_ERR_ARG;
     LaneGuard g(ctx);
     Lane* L = g.lane;
     if (!L) return HK_ERR_DEVICE;
-    size_t need = 3 * al256(n * sizeof(Affine<F>)) + al256(K * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) +
-                  al256(endo_tab_bytes<F>(n)) + al256(n * sizeof(F)) + 8192;
+    size_t need = 3 * k * al256(n * sizeof(Affine<F>)) + al256(K * sizeof(Fr)) + al256(k * n * sizeof(XYZZ<F>)) +
+                  al256(endo_tab_bytes<F>(n, k)) + al256(k * n * sizeof(F)) + 8192;
     HK_TRY(L->reserve(need));
-    const void *lod, *hid;
-    HK_TRY(to_device(L, lo, n * sizeof(Affine<F>), &lod));
-    HK_TRY(to_device(L, hi, n * sizeof(Affine<F>), &hid));
+    const Affine<F>*lod[FOLD_MAX], *hid[FOLD_MAX];
+    for (size_t y = 0; y < k; y++) {
+        const void* d;
+        HK_TRY(to_device(L, lo[y], n * sizeof(Affine<F>), &d));
+        lod[y] = (const Affine<F>*)d;
+        HK_TRY(to_device(L, hi[y], n * sizeof(Affine<F>), &d));
+        hid[y] = (const Affine<F>*)d;
+    }
     Fr* cd = L->alloc_n<Fr>(K);
     if (!cd) return HK_ERR_NOMEM;
     HK_HIP(hipMemcpyAsync(cd, coeffs, K * sizeof(Fr), is_device_ptr(coeffs) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           L->stream));
     if (!is_device_ptr(coeffs)) HK_HIP(hipStreamSynchronize(L->stream));      // a pageable caller buffer: done with it now
-    XYZZ<F>* tab = (XYZZ<F>*)L->alloc_n<unsigned char>(endo_tab_bytes<F>(n));
-    XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
-    F* pref = L->alloc_n<F>(n);
-    bool out_dev = is_device_ptr(out);
-    Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
+    XYZZ<F>* tab = (XYZZ<F>*)L->alloc_n<unsigned char>(endo_tab_bytes<F>(n, k));
+    XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(k * n);
+    F* pref = L->alloc_n<F>(k * n);
+    // one vector into a device buffer is normalised in place; otherwise into one array that is then handed out
+    bool direct = k == 1 && is_device_ptr(out[0]);
+    Affine<F>* od = direct ? (Affine<F>*)out[0] : L->alloc_n<Affine<F>>(k * n);
     if (!tab || !xy || !pref || !od) return HK_ERR_NOMEM;
-    HK_TRY(MsmRun<F>::fold_endo(L->stream, (const Affine<F>*)lod, (const Affine<F>*)hid, cd, neg_mask, (u32)n, tab, xy, pref, od));
-    if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+    HK_TRY(MsmRun<F>::fold_endo(L->stream, (u32)k, lod, hid, cd, neg_mask, (u32)n, tab, xy, pref, od));
+    if (!direct)
+        for (size_t y = 0; y < k; y++)
+            HK_HIP(hipMemcpyAsync(out[y], od + y * n, n * sizeof(Affine<F>),
+                                  is_device_ptr(out[y]) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, L->stream));
     HK_HIP(hipStreamSynchronize(L->stream));
     return HK_OK;
 }
@@ -895,7 +905,7 @@ hk_status Ops<C>::points_fold(hk_ctx* ctx, const void* lo, const void* hi, const
 template <class C>
 hk_status Ops<C>::points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs4, unsigned neg_mask,
                                  size_t n, void* out) {
-    return points_fold<Fq2>(ctx, lo, hi, coeffs4, neg_mask, n, out);
+    return points_fold<Fq2>(ctx, 1, &lo, &hi, coeffs4, neg_mask, n, &out);
 }
 
 // out[i] = lo[i] + (+-) coeffs2[0] * hi[i] + (+-) coeffs2[1] * phi(hi[i]) in G1: the G1 fold lo + c * hi with c split along the
@@ -903,7 +913,14 @@ hk_status Ops<C>::points_fold_g2(hk_ctx* ctx, const void* lo, const void* hi, co
 template <class C>
 hk_status Ops<C>::points_fold_g1(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs2, unsigned neg_mask,
                                  size_t n, void* out) {
-    return points_fold<Fq>(ctx, lo, hi, coeffs2, neg_mask, n, out);
+    return points_fold<Fq>(ctx, 1, &lo, &hi, coeffs2, neg_mask, n, &out);
+}
+
+template <class C>
+hk_status Ops<C>::points_fold_many(hk_ctx* ctx, int group, size_t k, const void* const* lo, const void* const* hi,
+                                   const void* coeffs, unsigned neg_mask, size_t n, void* const* out) {
+    return group == 1 ? points_fold<Fq>(ctx, k, lo, hi, coeffs, neg_mask, n, out)
+                      : points_fold<Fq2>(ctx, k, lo, hi, coeffs, neg_mask, n, out);
 }
 
 // z[i] = bits[i] ? 1 : 0 (Montgomery), then z[full_cols[k]] = full_vals[k]
@@ -1084,13 +1101,31 @@ hk_status Ops<C>::poseidon_path(hk_ctx* ctx, const void* consts, size_t n_consts
 template <class C>
 hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n_lhs, const void* const* rhs,
                                    size_t n_rhs, size_t n, void* out) {
+    return pairing_pairs(ctx, lhs, n_lhs, rhs, n_rhs, nullptr, nullptr, 0, n, out);
+}
+
+// pair_lhs == nullptr: every (lhs, rhs) pair, out[a * n_rhs + b]; else out[p] for the n_pairs listed pairs
+template <class C>
+hk_status Ops<C>::pairing_pairs(hk_ctx* ctx, const void* const* lhs, size_t n_lhs, const void* const* rhs, size_t n_rhs,
+                                const uint32_t* pair_lhs, const uint32_t* pair_rhs, size_t n_pairs, size_t n, void* out) {
     typedef typename Fq::Params P;
     typedef Fp12<P> GT;
-    size_t count = n_lhs * n_rhs;
-    if (count == 0 || count > 4096 || !out) return HK_ERR_ARG;
+    PairList pl;
+    pl.n = 0;
+    if (pair_lhs || pair_rhs) {
+        if (!pair_lhs || !pair_rhs || n_pairs == 0 || n_pairs > (size_t)PAIR_LIST_MAX || n_lhs > 255 || n_rhs > 255) return HK_ERR_ARG;
+        for (size_t k = 0; k < n_pairs; k++) {
+            if (pair_lhs[k] >= n_lhs || pair_rhs[k] >= n_rhs) return HK_ERR_ARG;
+            pl.a[k] = (unsigned char)pair_lhs[k];
+            pl.b[k] = (unsigned char)pair_rhs[k];
+        }
+        pl.n = (u32)n_pairs;
+    }
+    size_t count = pl.n ? pl.n : n_lhs * n_rhs;
+    if (count == 0 || count > 4096 || n_lhs == 0 || n_rhs == 0 || !out) return HK_ERR_ARG;
     if (n * count >= ((size_t)1 << 31)) return HK_ERR_ARG;
     // the per-step product trees run as grid (groups, count * steps): grid.y is a 16-bit quantity
-    if (count * PairRun<P>::steps() > 65535) return HK_ERR_ARG;
+    if (count * PairRun<P>::steps() > 65535 || n_rhs > 65535) return HK_ERR_ARG;
     if (n == 0) {                                                  // empty product: 1 (final_exponentiation(1) = 1)
         GT one = f12_one<P>();
         HK_HIP(hipSetDevice(ctx->device));
@@ -1104,7 +1139,7 @@ hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n
     Lane* L = g.lane;
     if (!L) return HK_ERR_DEVICE;
     size_t g1b = sizeof(Affine<Fq>), g2b = sizeof(Affine<Fq2>);
-    size_t mbytes = PairRun<P>::scratch_bytes((u32)n, (u32)count);
+    size_t mbytes = PairRun<P>::scratch_bytes((u32)n, (u32)count, (u32)n_rhs);
     size_t need = al256(n_lhs * n * g1b) + al256(n_rhs * n * g2b) + al256(mbytes) +
                   2 * al256(count * sizeof(GT)) + 8192;
     HK_TRY(L->reserve(need));
@@ -1117,7 +1152,7 @@ hk_status Ops<C>::pairing_products(hk_ctx* ctx, const void* const* lhs, size_t n
     if (!d1 || !d2 || !miller || !prod || !res) return HK_ERR_NOMEM;
     for (size_t a = 0; a < n_lhs; a++) HK_HIP(hipMemcpyAsync(d1 + a * n, lhs[a], n * g1b, h2d_kind(lhs[a]), s));
     for (size_t b = 0; b < n_rhs; b++) HK_HIP(hipMemcpyAsync(d2 + b * n, rhs[b], n * g2b, h2d_kind(rhs[b]), s));
-    HK_TRY(PairRun<P>::run(s, d1, d2, (u32)n, (u32)n_lhs, (u32)n_rhs, miller, prod, res));
+    HK_TRY(PairRun<P>::run(s, d1, d2, (u32)n, (u32)n_lhs, (u32)n_rhs, miller, prod, res, pl.n ? &pl : nullptr));
     HK_HIP(hipMemcpyAsync(out, res, count * sizeof(GT), is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     HK_HIP(hipStreamSynchronize(s));
     return HK_OK;

@@ -138,12 +138,6 @@ class Tipp:
         h = len(buf) // 2
         return buf[:h], buf[h:]
 
-    def _fold(self, group, lo, hi, coeff, n, out=None):
-        # the challenge split along an endomorphism: psi on G2 (66 doubling steps instead of 254), GLV's phi on G1 (128)
-        if group == 2:
-            return self.ctx.points_fold_g2(lo, hi, coeff, n=n, out=out)
-        return self.ctx.points_fold_g1(lo, hi, coeff, n=n, out=out)
-
     def _powers(self, x, n):
         out = [1] * n
         for i in range(1, n):
@@ -194,15 +188,15 @@ class Tipp:
             aL, aR, bL, bR = L(0), R(0), L(1), R(1)
             v1L, v1R, v2L, v2R = L(2), R(2), L(3), R(3)
             w1L, w1R, w2L, w2R = L(4), R(4), L(5), R(5)
-            # all ten multi-pairings of the round in two batched calls, issued together
+            # all ten multi-pairings of the round in ONE batched call: ten (lhs, rhs) pairs out of 6 x 6, every G2 vector's
+            # Miller lines computed once
             t0 = time.perf_counter()
-            fa = go(ctx.pairing_products, [aR, aL], [v1L, v2L, bL, v1R, v2R, bR], h)
-            fw = go(ctx.pairing_products, [w1R, w2R, w1L, w2L], [bL, bR], h)
-            pa, pw = fa.result(), fw.result()
+            pp = ctx.pairing_pairs([aR, aL, w1R, w2R, w1L, w2L], [v1L, v2L, bL, v1R, v2R, bR],
+                                   [(0, 0), (2, 2), (0, 1), (3, 2), (0, 2), (1, 3), (4, 5), (1, 4), (5, 5), (1, 5)], h)
             t1 = time.perf_counter()
             D = F.decode
-            TL = F.mul(D(pa[0, 0]), D(pw[0, 0])); UL = F.mul(D(pa[0, 1]), D(pw[1, 0])); ZL = D(pa[0, 2])
-            TR = F.mul(D(pa[1, 3]), D(pw[2, 1])); UR = F.mul(D(pa[1, 4]), D(pw[3, 1])); ZR = D(pa[1, 5])
+            TL = F.mul(D(pp[0]), D(pp[1])); UL = F.mul(D(pp[2]), D(pp[3])); ZL = D(pp[4])
+            TR = F.mul(D(pp[5]), D(pp[6])); UR = F.mul(D(pp[7]), D(pp[8])); ZR = D(pp[9])
             tr.absorb(b"round", *(F.encode(x) for x in (TL, UL, ZL, TR, UR, ZR)))
             c = tr.challenge(b"c")
             c_inv = pow(c, -1, r)
@@ -210,9 +204,9 @@ class Tipp:
             challenges.append(c)
             nxt = pos + m                                                   # the folds go right behind the current vectors
             t2 = time.perf_counter()
-            folds = [go(self._fold, g, lo, hi, cc, h, win(k, nxt, h)) for k, (g, lo, hi, cc) in enumerate((
-                (1, aL, aR, c), (2, bL, bR, c_inv), (2, v1L, v1R, c_inv), (2, v2L, v2R, c_inv),
-                (1, w1L, w1R, c), (1, w2L, w2R, c)))]
+            # the three G1 folds share c, the three G2 folds c^-1: one batched call per group, issued together
+            folds = [go(ctx.points_fold_many, 1, [aL, w1L, w2L], [aR, w1R, w2R], c, h, [win(k, nxt, h) for k in (0, 4, 5)]),
+                     go(ctx.points_fold_many, 2, [bL, v1L, v2L], [bR, v1R, v2R], c_inv, h, [win(k, nxt, h) for k in (1, 2, 3)])]
             for f in folds:
                 f.result()
             self.round_times.append((m, t1 - t0, t2 - t1, time.perf_counter() - t2))

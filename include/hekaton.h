@@ -175,6 +175,13 @@ hk_status hk_scalar_pairing_g2(hk_ctx* ctx, const void* points, const void* scal
 hk_status hk_multi_pairing(hk_ctx* ctx, const void* g1, const void* g2, size_t n, void* gt_out);
 hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2,
                               size_t n_rhs, size_t n, void* gt_out);
+/* hk_pairing_pairs: the same batched launch for a LIST of (lhs vector, rhs vector) pairs instead of the full grid:
+ * gt_out[p] = pairing(lhs_g1[pair_lhs[p]], rhs_g2[pair_rhs[p]]), p < n_pairs <= 64.  One GIPA round of the TIPA prover
+ * (ark-ip-proofs `gipa` under distributed-prover/src/aggregation.rs:340) needs ten inner products between six G1 and six
+ * G2 half-vectors - e(A_R, v1_L), e(w1_R, B_L), ... - each rhs vector's Miller lines are computed once and shared by the
+ * pairs that use it.  pair_lhs, pair_rhs [h]: n_pairs indices into lhs_g1 / rhs_g2. */
+hk_status hk_pairing_pairs(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2, size_t n_rhs,
+                           const uint32_t* pair_lhs, const uint32_t* pair_rhs, size_t n_pairs, size_t n, void* gt_out);
 hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt);
 /* gt_out[i] = gt_in[i]^scalars[i] in GT - `Commitment * scalar` (distributed-prover/src/aggregation.rs:171-174,328-332) and
  * the six GT powers per round of the TIPA verifier; one wavefront per element.  gt_in, gt_out [h|d]: n GT elements;
@@ -204,6 +211,14 @@ void hk_keccak_f1600(uint64_t* state25);
  * ~128-bit parts - the folds `A' = A_L + c A_R`, `w' = w_L + c w_R` of a round.  128 doubling steps instead of 254. */
 hk_status hk_points_fold_g1(hk_ctx* ctx, const void* lo, const void* hi, const void* coeffs2_mont, unsigned neg_mask, size_t n,
                             void* out);
+/* k <= 4 folds that share ONE scalar, as the folds of one GIPA round do (`A' = A_L + c A_R`, `w1' = ..`, `w2' = ..` with c;
+ * `B'`, `v1'`, `v2'` with c^-1: ark-ip-proofs `gipa`, reached from distributed-prover/src/aggregation.rs:340 - there one rayon
+ * sweep per vector): out[y][i] = lo[y][i] + c * hi[y][i], one launch and one normalisation for all k vectors.
+ * lo, hi, out [h]: k pointers, each [h|d] to n packed affine points; coeffs / neg_mask as in hk_points_fold_g1 / _g2. */
+hk_status hk_points_fold_many_g1(hk_ctx* ctx, size_t k, const void* const* lo, const void* const* hi, const void* coeffs2_mont,
+                                 unsigned neg_mask, size_t n, void* const* out);
+hk_status hk_points_fold_many_g2(hk_ctx* ctx, size_t k, const void* const* lo, const void* const* hi, const void* coeffs4_mont,
+                                 unsigned neg_mask, size_t n, void* const* out);
 
 /* ---- MSM over a RESIDENT base set ----------------------------------------------------------------------
  * Bases that are key material (the KZG / commitment-key powers of the aggregator's SRS, any static query) are

@@ -149,3 +149,34 @@ def test_k_lanes_per_element_equals_one_lane_per_element(cname, group, ctx_bn254
     # lo + 0 * hi = lo, lo + 1 * hi where hi = O is lo
     assert np.array_equal(split[5], lo)
     assert np.array_equal(split[2][5 * pb:6 * pb], np.zeros(pb, np.uint8))
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "bn254"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_folds_that_share_a_scalar_in_one_call(cname, group, ctx_bn254, ctx_bls):
+    """hk_points_fold_many_g1 / _g2 (three vector pairs, one scalar, one launch) = three hk_points_fold calls, into host
+    arrays and into device buffers."""
+    from hekaton_system_amd.capi import DeviceBuffer
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    cp, fc, cd = CURVES[cname], FrCodec(cname), Codec(CURVES[cname])
+    gen = cp.g1_gen if group == 1 else cp.g2_gen
+    pb = ctx.g1_bytes if group == 1 else ctx.g2_bytes
+    rnd = random.Random(21 + group)
+    n = 37
+    vec = (cd.g1_vec if group == 1 else cd.g2_vec)([gen])
+    mk = lambda: ctx.fixed_base(group, vec, fc.enc([rnd.randrange(1, cp.r) for _ in range(n)])).copy()
+    los, his = [mk() for _ in range(3)], [mk() for _ in range(3)]
+    his[1][:pb] = 0
+    los[2][pb:2 * pb] = 0
+    c = rnd.randrange(cp.r)
+    fold = ctx.points_fold_g1 if group == 1 else ctx.points_fold_g2
+    want = [fold(lo, hi, c, n=n).copy() for lo, hi in zip(los, his)]
+    outs = [np.zeros(n * pb, np.uint8) for _ in range(3)]
+    ctx.points_fold_many(group, los, his, c, n, outs)
+    for y in range(3):
+        assert np.array_equal(outs[y], want[y]), (cname, group, y)
+    dev = [DeviceBuffer(ctx, n * pb) for _ in range(3)]
+    ctx.points_fold_many(group, los, his, c, n, dev)
+    for y in range(3):
+        assert np.array_equal(np.frombuffer(dev[y].to_host(), np.uint8), want[y]), (cname, group, y, "device out")
+        dev[y].free()

@@ -77,6 +77,12 @@ def test_multi_pairing_1024_bilinearity_and_cross_terms(ctx_bn254):
             want = T.f12_pow(e_gen, sum(x * y for x, y in zip(ka, kb)) % cp.r)
             assert E.f12_dec(out[i, j].tobytes()) == T.f12_flat(want), (i, j)
     assert E.f12_dec(out[0, 0].tobytes()) == got
+    # a LIST of pairs out of the 4 x 4 grid (hk_pairing_pairs: the ten cross terms of a GIPA round), repeats allowed
+    pairs = [(0, 0), (3, 1), (1, 3), (2, 2), (3, 1), (0, 3)]
+    sel = ctx_bn254.pairing_pairs([v for _, v in lhs], [v for _, v in rhs], pairs)
+    assert sel.shape == (len(pairs), ctx_bn254.gt_bytes)
+    for k, (i, j) in enumerate(pairs):
+        assert np.array_equal(sel[k], out[i, j]), (k, i, j)
 
 
 @pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
