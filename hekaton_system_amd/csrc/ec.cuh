@@ -201,10 +201,11 @@ HK_HD XYZZ<F> ec_mul_limbs(const XYZZ<F>& p, const u32 (&k)[NL]) {
     return acc;
 }
 
-// ---- inversion (Fermat) and normalisation to affine -----------------------------------------
+// ---- inversion and normalisation to affine ---------------------------------------------------
+// a^(p-2): the first form, kept as the cross-check of the host tests (tests/test_capi_cpu.py)
 template <class P>
-HK_HD Fp<P> fp_inv(const Fp<P>& a) {
-    // a^(p-2); exponent limbs = modulus - 2 with borrow propagation
+HK_HD Fp<P> fp_inv_fermat(const Fp<P>& a) {
+    // exponent limbs = modulus - 2 with borrow propagation
     u32 ex[P::N];
     u32 borrow = 2;
     for (int i = 0; i < P::N; i++) {
@@ -221,6 +222,87 @@ HK_HD Fp<P> fp_inv(const Fp<P>& a) {
         }
     }
     return result;
+}
+
+// Binary extended Euclid without data-dependent branches inside an iteration (the plain form of Pornin, "Optimized Binary
+// GCD for Modular Inversion", algorithm 1): with b odd,
+//     if a is odd: { if a < b: (a, u, b, v) <- (b, v, a, u);  a <- a - b;  u <- u - v mod p }   a <- a / 2;  u <- u / 2 mod p
+// keeps a = u y, b = v y (mod p) and ends with a = 0, b = gcd = 1, v = 1 / y after at most 2 len(p) - 1 iterations
+// (~1.4 len(p) typically; a lane leaves the loop when ITS a is 0).  An iteration is ~14 N word instructions against the
+// ~2 N^2 + of a Montgomery product, and there are fewer of them than the 1.5 len(p) products of a^(p-2): the inversion
+// is the serial tail of every normalisation to affine (k_batch_affine after each fold / sweep, k_to_affine, k_finish) and
+// of the final exponentiation - 0.35 ms per call on BN254 and 1.7 ms on BLS12-381 as a^(p-2).
+// Works on the plain integer y = a R mod p of the Montgomery value; 1 / y = a^-1 R^-1, times R^3 (one Montgomery product
+// by R^2 R^2 / R) gives a^-1 R.  0 maps to 0, as a^(p-2) does.
+template <class P>
+HK_RARE Fp<P> fp_inv(const Fp<P>& a_in) {
+    constexpr int N = P::N;
+    Fp<P> y = Fp<P>::canon(a_in);
+    if (y.is_zero()) return Fp<P>::zero();
+    u32 a[N], b[N], u[N], v[N];
+    HK_UNROLL for (int i = 0; i < N; i++) { a[i] = y.v[i]; b[i] = P::MOD[i]; u[i] = i == 0; v[i] = 0; }
+    for (;;) {
+        u32 nz = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) nz |= a[i];
+        if (!nz) break;
+        u32 odd = 0u - (a[0] & 1u);                      // all-ones when a is odd
+        // d = a - b, borrow -> a < b
+        u32 d[N];
+        u64 br = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            u64 t = (u64)a[i] - b[i] - br;
+            d[i] = (u32)t;
+            br = (t >> 32) & 1u;
+        }
+        u32 lt = (0u - (u32)br) & odd;                   // swap: a odd and a < b
+        u32 ge = odd & ~lt;
+        // a odd, a >= b: a <- d;   a odd, a < b: b <- a, a <- -d (= b - a);   a even: unchanged
+        u64 c = 1;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            c += (u64)(u32)~d[i];
+            u32 nd = (u32)c;
+            c >>= 32;
+            u32 ai = a[i];
+            a[i] = (d[i] & ge) | (nd & lt) | (ai & ~odd);
+            b[i] = (ai & lt) | (b[i] & ~lt);
+        }
+        // (u, v) <- (v, u) on a swap, then u <- u - v mod p when a was odd
+        u64 sb = 0;
+        u32 w[N];
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            u32 ui = u[i], vi = v[i];
+            u32 un = (vi & lt) | (ui & ~lt);
+            v[i] = (ui & lt) | (vi & ~lt);
+            u64 t = (u64)un - (v[i] & odd) - sb;
+            w[i] = (u32)t;
+            sb = (t >> 32) & 1u;
+        }
+        u32 fix = 0u - (u32)sb;                          // negative: add p back
+        u64 cc = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            cc += (u64)w[i] + (P::MOD[i] & fix);
+            w[i] = (u32)cc;
+            cc >>= 32;
+        }
+        // a <- a / 2;  u <- u / 2 mod p = (u odd ? u + p : u) >> 1, the sum kept with its carry bit
+        u32 uo = 0u - (w[0] & 1u);
+        u64 hc = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            hc += (u64)w[i] + (P::MOD[i] & uo);
+            w[i] = (u32)hc;
+            hc >>= 32;
+        }
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            u32 hi_u = i + 1 < N ? w[i + 1] : (u32)hc;
+            u32 hi_a = i + 1 < N ? a[i + 1] : 0u;
+            u[i] = (w[i] >> 1) | (hi_u << 31);
+            a[i] = (a[i] >> 1) | (hi_a << 31);
+        }
+    }
+    Fp<P> r;
+    HK_UNROLL for (int i = 0; i < N; i++) r.v[i] = v[i];
+    Fp<P> r3 = f_mul_ni(Fp<P>::r2(), Fp<P>::r2());
+    return f_mul_ni(r, r3);
 }
 template <class P>
 HK_HD Fp2<P> fp_inv(const Fp2<P>& a) {

@@ -10,6 +10,9 @@ using namespace hk;
 template <class F> static void ld(F& f, const void* p) { memcpy(&f, p, sizeof(F)); }
 template <class F> static void st(void* p, const F& f) { memcpy(p, &f, sizeof(F)); }
 
+template <class P> static Fp<P> inv_fermat(const Fp<P>& x) { return fp_inv_fermat(x); }
+template <class P> static Fp2<P> inv_fermat(const Fp2<P>& x) { return fp_inv(x); }
+
 template <class F>
 static void field_op(int op, const void* a, const void* b, void* out) {
     F x, y, r; ld(x, a); ld(y, b);
@@ -20,6 +23,7 @@ static void field_op(int op, const void* a, const void* b, void* out) {
         case 3: r = F::neg(x); break;
         case 4: r = fp_inv(x); break;
         case 5: r = F::sqr(x); break;
+        case 6: r = inv_fermat(x); break;
         default: r = F::zero();
     }
     st(out, r);

@@ -104,6 +104,29 @@ def test_product_field_and_curve_arithmetic_vs_golden(shim):
                 assert gop(ids[cname][key], 0, p, p, len(p)) == c["dbl_p"]     # P + P corner
 
 
+def test_binary_inversion_equals_fermat_and_python(shim):
+    """csrc/ec.cuh `fp_inv` (binary extended Euclid on the Montgomery value's integer) against a^(p-2) from the same
+    source and against Python's modular inverse, on edge values and random ones, all four prime fields; 0 -> 0."""
+    import random
+    from oracle.pyref.params import CURVES
+    rnd = random.Random(99)
+    for cname, (fr_id, fq_id) in (("bn254", (0, 1)), ("bls12_381", (2, 3))):
+        cp = CURVES[cname]
+        for fid, mod, R in ((fr_id, cp.r, cp.fr_R), (fq_id, cp.q, cp.fq_R)):
+            nb = 32 if mod.bit_length() <= 256 else 48
+            vals = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, 1 << 64, (1 << (mod.bit_length() - 1)) - 1] + \
+                   [rnd.randrange(1, mod) for _ in range(200)]
+            for x in vals:
+                a = (x * R % mod).to_bytes(nb, "little")
+                out, ref = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+                shim.shim_field_op(fid, 4, a, a, out)
+                shim.shim_field_op(fid, 6, a, a, ref)
+                got = int.from_bytes(out.raw, "little") % mod
+                assert got == int.from_bytes(ref.raw, "little") % mod, (cname, fid, x)
+                want = pow(x, -1, mod) * R % mod if x else 0
+                assert got == want, (cname, fid, x)
+
+
 def test_msm_window_count_is_the_smallest_that_holds_every_scalar(tmp_path_factory):
     """csrc/msm.cuh `msm_num_windows` (host code, compiled here with g++): with the signed-digit recoding
     s' = s + sum_{w<W} 2^(cw+c-1), W windows are enough iff (r - 1) + that constant < 2^(cW).  The plan must pick the
