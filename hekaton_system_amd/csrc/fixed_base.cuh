@@ -95,15 +95,17 @@ k_scalar_mul_each(const Affine<F>* __restrict__ pts, const Fr* __restrict__ scal
     st_vec(&out[i], ec_mul_limbs(p, s.v));
 }
 
-// XYZZ -> affine for n points, FB_CHUNK per lane, one field inversion per lane.
+// XYZZ -> affine for n points, `chunk` per lane, one field inversion per lane (Montgomery's trick inside the lane).  The
+// caller picks chunk = 1 while that still leaves at most one wave per SIMD (n <= 65536: a lane's serial work is then the
+// inversion plus 8 products instead of the inversion plus 8 per chunk element), FB_CHUNK for long vectors.
 // scratch: n coordinate-field elements (prefix products of zzz).
 template <class F>
 __global__ void __launch_bounds__(64)
-k_batch_affine(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, F* __restrict__ scratch, u32 n) {
+k_batch_affine(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, F* __restrict__ scratch, u32 n, u32 chunk) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 lo = t * FB_CHUNK;
-    if (lo >= n) return;
-    u32 hi = min(lo + (u32)FB_CHUNK, n);
+    if ((size_t)t * chunk >= n) return;
+    u32 lo = t * chunk;
+    u32 hi = min(lo + chunk, n);
     F acc = F::one();
     for (u32 i = lo; i < hi; i++) {
         st_vec(&scratch[i], acc);

@@ -158,8 +158,10 @@ hk_status MsmRun<F>::to_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out,
 template <class F>
 hk_status MsmRun<F>::batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, F* pref, u32 n) {
     if (n == 0) return HK_OK;
-    u32 lanes = (n + FB_CHUNK - 1) / FB_CHUNK;
-    hipLaunchKernelGGL((k_batch_affine<F>), dim3((lanes + 63) / 64), dim3(64), 0, s, in, out, pref, n);
+    u32 chunk = (n + 65535) / 65536;                       // 1 up to one wave per SIMD, then longer serial runs per lane
+    if (chunk > (u32)FB_CHUNK) chunk = FB_CHUNK;
+    u32 lanes = (n + chunk - 1) / chunk;
+    hipLaunchKernelGGL((k_batch_affine<F>), dim3((lanes + 63) / 64), dim3(64), 0, s, in, out, pref, n, chunk);
     HK_HIP(hipGetLastError());
     return HK_OK;
 }
