@@ -131,7 +131,7 @@ class Tipp:
         self.F = GtField(curve)
         self.r = CURVE_PARAMS[curve]["r"]
         self.com = TIPPCommitment(ctx, curve)
-        self.pool = ThreadPoolExecutor(max_workers=6)      # independent GPU calls of a round go out together (one lane each)
+        self.pool = ThreadPoolExecutor(max_workers=10)     # independent GPU calls of a phase go out together (one lane each)
 
     # ---- helpers ----------------------------------------------------------------------------------------
     def _halves(self, buf, size):
@@ -272,28 +272,27 @@ class Tipp:
         fvz = ipa_polynomial_eval(chi_rev, 1, z, r)
         fwz = pow(z, n, r) * ipa_polynomial_eval(ch_rev, r_inv, z, r) % r
         neg = lambda x: (r - x) % r
-        f_inst = go(ctx.pairing_products, [a, w1, w2], [b, v1, v2], 1)
-        # v:  e(g, v' - f_v(z) h) = e(g^tau - z g, pi)   <=>   e(g, v' - f_v(z) h) * e(z g - g^tau, pi) = 1
+        f_inst = go(ctx.pairing_pairs, [a, w1, w2], [b, v1, v2], [(0, 0), (0, 1), (1, 0), (0, 2), (2, 0)], 1)
+        # Each single-element combination is lo + c * hi: the endomorphism-split fold (K lanes per element, hk_points_fold)
+        # instead of a joint 254-step chain (hk_points_lincomb: 4.5 ms in G1, 13 ms in G2 for ONE element).
+        # v:  e(g, v' - f_v(z) h) = e(g^tau - z g, pi)
         v_checks = []
         for key, vfin, pi in (("g_alpha", v1, proof["open_v"][0]), ("g_beta", v2, proof["open_v"][1])):
-            v_checks.append((go(ctx.points_lincomb, 2, [vfin, vk["h"]], fc.enc([1, neg(fvz)]), 1),
-                             go(ctx.points_lincomb, 1, [vk["g"], vk[key]], fc.enc([z, neg(1)]), 1), pi))
+            v_checks.append((go(ctx.points_fold_g2, vfin, vk["h"], neg(fvz), 1),
+                             go(ctx.points_fold_g1, vk[key], vk["g"], neg(z), 1), pi))
         # w:  e(w' - f_w(z) g, h) = e(pi, h^tau - z h)
         w_checks = []
         for key, wfin, pi in (("h_alpha", w1, proof["open_w"][0]), ("h_beta", w2, proof["open_w"][1])):
-            w_checks.append((go(ctx.points_lincomb, 1, [wfin, vk["g"]], fc.enc([1, neg(fwz)]), 1),
-                             go(ctx.points_lincomb, 2, [vk[key], vk["h"]], fc.enc([1, neg(z)]), 1), pi))
-        f_v = [go(ctx.pairing_products, [vk["g"], l1.result()], [l2.result(), pi], 1) for l2, l1, pi in v_checks]
-        f_w = [go(ctx.pairing_products, [l1.result(), pi], [vk["h"], r2.result()], 1) for l1, r2, pi in w_checks]
+            w_checks.append((go(ctx.points_fold_g1, wfin, vk["g"], neg(fwz), 1),
+                             go(ctx.points_fold_g2, vk[key], vk["h"], neg(z), 1), pi))
+        f_v = [go(ctx.pairing_pairs, [vk["g"], l1.result()], [l2.result(), pi], [(0, 0), (1, 1)], 1) for l2, l1, pi in v_checks]
+        f_w = [go(ctx.pairing_pairs, [l1.result(), pi], [vk["h"], r2.result()], [(0, 0), (1, 1)], 1) for l1, r2, pi in w_checks]
         pi_ = f_inst.result()
-        ok = D(pi_[0, 0]) == Z                                                  # the folded instance: e(a, b) = Z
-        ok &= F.mul(D(pi_[0, 1]), D(pi_[1, 0])) == T and F.mul(D(pi_[0, 2]), D(pi_[2, 0])) == U
-        for f in f_v:                                                           # e(g, lhs2) == conj(e(lhs1, pi))
+        ok = D(pi_[0]) == Z                                                     # the folded instance: e(a, b) = Z
+        ok &= F.mul(D(pi_[1]), D(pi_[2])) == T and F.mul(D(pi_[3]), D(pi_[4])) == U
+        for f in f_v + f_w:                                                     # both sides of each KZG check
             pr = f.result()
-            ok &= D(pr[0, 0]) == F.conj(D(pr[1, 1]))
-        for f in f_w:                                                           # e(lhs1, h) == e(pi, rhs2)
-            pr = f.result()
-            ok &= D(pr[0, 0]) == D(pr[1, 1])
+            ok &= D(pr[0]) == D(pr[1])
         return bool(ok)
 
 
