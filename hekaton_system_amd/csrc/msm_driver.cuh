@@ -92,10 +92,6 @@ struct PairRun {
     static u32 steps();          // line-evaluation steps of the Miller loop (the factor of `count` in the tree launches' grid.y)
     // out[e] = in[e]^scalars[e] (GT powers; device pointers)
     static hk_status gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out);
-    // out[j][i] = (neg_mask bit j ? - : +) psi^j(pts[i]), j = 0..3 (device pointers; G2 endomorphism, pairing.cuh g2_psi)
-    // out[j][i] = (neg_mask bit j ? - : +) phi^j(pts[i]), j = 0, 1 (G1 endomorphism (x, y) -> (BETA x, y))
-    static hk_status phi2(hipStream_t s, const Affine<Fp<P>>* pts, u32 n, u32 neg_mask, Affine<Fp<P>>* const* out);
-    static hk_status psi4(hipStream_t s, const Affine<Fp2<P>>* pts, u32 n, u32 neg_mask, Affine<Fp2<P>>* const* out);        // size of `miller` (lines + tree buffers, or Miller values)
 };
 
 }  // namespace hk

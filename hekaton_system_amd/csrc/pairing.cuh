@@ -104,46 +104,9 @@ HK_HD Affine<Fp2<P>> g2_psi(const Affine<Fp2<P>>& q) {
     return r;
 }
 
-#if defined(__HIPCC__)
-// out_j[i] = (neg_mask bit j ? - : +) psi^j(pts[i]),  j = 0..3
-template <class P>
-__global__ void __launch_bounds__(64)
-k_points_psi4(const Affine<Fp2<P>>* __restrict__ pts, u32 n, u32 neg_mask, Affine<Fp2<P>>* __restrict__ o0,
-              Affine<Fp2<P>>* __restrict__ o1, Affine<Fp2<P>>* __restrict__ o2, Affine<Fp2<P>>* __restrict__ o3) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine<Fp2<P>> t = ld_vec(&pts[i]);
-    const bool inf = t.is_inf();                                   // psi(O) = O, -O = O: written as (0, 0) explicitly
-    Affine<Fp2<P>>* outs[4] = {o0, o1, o2, o3};
-    HK_NOUNROLL for (int j = 0; j < 4; j++) {
-        if (j && !inf) t = g2_psi(t);
-        Affine<Fp2<P>> w = t;
-        if (!inf && ((neg_mask >> j) & 1)) w.y = Fp2<P>::neg(w.y);
-        st_vec(&outs[j][i], w);
-    }
-}
-// out_j[i] = (neg_mask bit j ? - : +) phi^j(pts[i]), j = 0, 1, phi(x, y) = (BETA x, y): the GLV endomorphism of G1
-template <class P>
-__global__ void __launch_bounds__(64)
-k_points_phi2(const Affine<Fp<P>>* __restrict__ pts, u32 n, u32 neg_mask, Affine<Fp<P>>* __restrict__ o0,
-              Affine<Fp<P>>* __restrict__ o1) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    typedef Fp<P> Fq;
-    Affine<Fq> t = ld_vec(&pts[i]);
-    const bool inf = t.is_inf();
-    Affine<Fq> a = t, b = t;
-    if (!inf) {
-        Fq beta;
-        for (int k = 0; k < P::N; k++) beta.v[k] = TowerParams<P>::BETA[k];
-        b.x = Fq::mul(t.x, beta);
-        if (neg_mask & 1) a.y = Fq::neg(a.y);
-        if (neg_mask & 2) b.y = Fq::neg(b.y);
-    }
-    st_vec(&o0[i], a);
-    st_vec(&o1[i], b);
-}
-#endif
+// (Round 2 applied psi / phi in kernels of their own, k_points_psi4 / k_points_phi2; the first form of k_points_psi4 is the
+// kernel hipcc miscompiled - DESIGN.md section 3b, tests/golden/isa/.  The images are now built inside the fold kernels of
+// endo.cuh, which call g2_psi / EndoOf<F>::apply per element.)
 
 // Miller value of ONE pair (1 when either member is infinity: ark's multi_miller_loop skips such pairs)
 template <class P>

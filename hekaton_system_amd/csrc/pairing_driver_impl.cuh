@@ -25,27 +25,9 @@ hk_status PairRun<P>::gt_pow(hipStream_t s, const Fp12<P>* in, const void* scala
 }
 
 template <class P>
-hk_status PairRun<P>::phi2(hipStream_t s, const Affine<Fp<P>>* pts, u32 n, u32 neg_mask, Affine<Fp<P>>* const* out) {
-    if (n == 0) return HK_OK;
-    hipLaunchKernelGGL((k_points_phi2<P>), dim3((n + 63) / 64), dim3(64), 0, s, pts, n, neg_mask, out[0], out[1]);
-    HK_DBG(s, "k_points_phi2");
-    HK_HIP(hipGetLastError());
-    return HK_OK;
-}
-
-template <class P>
-hk_status PairRun<P>::psi4(hipStream_t s, const Affine<Fp2<P>>* pts, u32 n, u32 neg_mask, Affine<Fp2<P>>* const* out) {
-    if (n == 0) return HK_OK;
-    hipLaunchKernelGGL((k_points_psi4<P>), dim3((n + 63) / 64), dim3(64), 0, s, pts, n, neg_mask, out[0], out[1], out[2], out[3]);
-    HK_DBG(s, "k_points_psi4");
-    HK_HIP(hipGetLastError());
-    return HK_OK;
-}
-
-template <class P>
 size_t PairRun<P>::max_private_bytes() {
     const void* ks[] = {(const void*)k_pair_lines<P>, (const void*)k_pair_tree_lines<P>, (const void*)k_pair_tree<P>,
-                        (const void*)k_pair_horner<P>, (const void*)k_points_psi4<P>, (const void*)k_points_phi2<P>,
+                        (const void*)k_pair_horner<P>,
                         (const void*)k_gt_pow<P, typename ScalarOfQ<P>::type>};
     const void* serial[] = {(const void*)k_pair_miller<P>, (const void*)k_f12_product<P>, (const void*)k_final_exp<P>};
     size_t m = 0;

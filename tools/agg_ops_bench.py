@@ -89,6 +89,7 @@ def main():
         proof = T.prove(srs, A, B, twist, com, z)
         t_prove = time.time() - t0
         vk = tipa.verifier_key(ctx, curve, srs)
+        T.verify(vk, com, z, twist, proof)                  # warm (the first call creates the lanes of its ten concurrent calls)
         t0 = time.time()
         ok = T.verify(vk, com, z, twist, proof)
         t_verify = time.time() - t0
