@@ -191,6 +191,8 @@ k_points_fold_endo(const Affine<F>* __restrict__ lo, const Affine<F>* __restrict
     }
     st_vec(&out[i], ec_madd_ni(acc, l));
 }
+#endif  // __HIPCC__ (the one-lane kernels)
+
 // ---- K lanes per element ------------------------------------------------------------------------------------------------
 // A sweep over a few hundred elements is ONE wave per SIMD at most: its time is the length of one lane's dependent chain,
 // and a chain of 68 / 131 x (double + add) cannot be shortened on one lane.  So for short vectors (n K <= SPLIT_MAX_LANES)
@@ -286,10 +288,26 @@ template <class F> inline size_t endo_tab_bytes(size_t n, size_t vectors = 1) {
     return (one > split ? one : split) + 256;
 }
 
+// Signed 4-bit digits without a carry chain at run time: m' = m + 0x88..8 over ND nibbles (ND = ceil(bits / 4) + 1, so the
+// top nibble of m' is 8 or 9), digit d = nibble_d(m') - 8 in -8 .. 7, and m = sum_d digit_d 16^d.
+template <int ND>
+HK_HD void split_bias(u32 (&m)[6]) {
+    u64 carry = 0;
+    for (int l = 0; l < 6; l++) {
+        int nib = ND - 8 * l;                                // nibbles of the bias inside limb l
+        u32 bias = nib >= 8 ? 0x88888888u : nib <= 0 ? 0u : (0x88888888u & ((1u << (4 * nib)) - 1u));
+        carry += (u64)m[l] + bias;
+        m[l] = (u32)carry;
+        carry >>= 32;
+    }
+}
+HK_HD int split_digit(const u32 (&m)[6], int d) { return (int)((m[d >> 3] >> (4 * (d & 7))) & 15u) - 8; }
+template <class F> struct SplitDigits { static constexpr int ND = (EndoOf<F>::STEPS + 3) / 4 + 1; };
+
+#if defined(__HIPCC__)
 // out[i] = (lo ? lo[i] : 0) + s_i * pts[i].   UNIFORM: one scalar for the whole vector, split on the host: `scalars` = K
 // Montgomery magnitudes, neg_all = their sign mask (the fold of a TIPA round);  else scalars[i], split here by every lane
 // of the element (the split is ~300 integer products: cheaper than passing it between lanes).
-// Signed 4-bit digits without a carry chain at run time: with m' = |k_j| + 0x88..8, digit d = nibble_d(m') - 8 in -8 .. 7.
 // grid: (ceil(n K / 64), vectors) blocks of 64 lanes; lane t: element t / K, part t % K; vector y = blockIdx.y reads
 // v.lo[y] / v.pts[y] and writes out[y n ..) (UNIFORM: the same scalar for every vector - the folds of one TIPA round).
 // tab: vectors x split_tab_bytes(n).
@@ -301,7 +319,7 @@ __global__ void __launch_bounds__(64)
 k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, u32 n, EndoSplit<EndoOf<F>::K> E,
                    Jac<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
     constexpr int K = EndoOf<F>::K;
-    constexpr int ND = (EndoOf<F>::STEPS + 3) / 4 + 1;          // nibbles of m'
+    constexpr int ND = SplitDigits<F>::ND;                        // nibbles of m'
     __shared__ Jac<F> sh[64];
     const Affine<F>* __restrict__ lo = v.lo[blockIdx.y];
     const Affine<F>* __restrict__ pts = v.pts[blockIdx.y];
@@ -332,15 +350,7 @@ k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, 
             }
             negate = (neg >> j) & 1u;
         }
-        // m' = m + 0x88..8 over ND nibbles
-        u64 carry = 0;
-        HK_UNROLL for (int l = 0; l < 6; l++) {
-            int nib = ND - 8 * l;                                // nibbles of the bias inside limb l
-            u32 bias = nib >= 8 ? 0x88888888u : nib <= 0 ? 0u : (0x88888888u & ((1u << (4 * nib)) - 1u));
-            carry += (u64)m[l] + bias;
-            m[l] = (u32)carry;
-            carry >>= 32;
-        }
+        split_bias<ND>(m);
         Affine<F> q = ld_vec(&pts[i]);
         if (!q.is_inf()) {
             HK_NOUNROLL for (u32 k = 0; k < j; k++) q = EndoOf<F>::apply(q);
@@ -356,7 +366,7 @@ k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, 
         }
         bool q_inf = q.is_inf();
         HK_NOUNROLL for (int d = ND - 1; d >= 0; d--) {
-            int dig = (int)((m[d >> 3] >> (4 * (d & 7))) & 15u) - 8;
+            int dig = split_digit(m, d);
             bool idle = q_inf || (dig == 0 && acc.is_inf());
             if (__all(idle)) continue;                           // leading zero digits of the whole wave
             HK_NOUNROLL for (int r = 0; r < 4; r++) acc = jac_dbl_ni(acc);

@@ -78,7 +78,45 @@ static void multi_pairing(const void* g1, const void* g2, size_t n, const PairLo
     st(out, f12_canon(pair_final_exp<P>(acc, w)));
 }
 
+// |k| * P exactly as one lane of k_points_mul_split computes it (csrc/endo.cuh): table 1P .. 8P by doublings and mixed adds,
+// the magnitude biased by 0x88..8, signed 4-bit digits from the top, four Jacobian doublings and one table add per digit
+template <class F>
+static void split_mul(const void* pt, const unsigned* mag, void* out) {
+    constexpr int ND = SplitDigits<F>::ND;
+    Affine<F> q; ld(q, pt);
+    u32 m[6];
+    for (int l = 0; l < 6; l++) m[l] = mag[l];
+    split_bias<ND>(m);
+    Jac<F> tab[SPLIT_TABLE];
+    Jac<F> acc = Jac<F>::inf();
+    if (!q.is_inf()) {
+        tab[0] = Jac<F>::from_affine(q);
+        for (int k = 2; k <= SPLIT_TABLE; k++) tab[k - 1] = (k & 1) ? jac_madd_ni(tab[k - 2], q) : jac_dbl_ni(tab[k / 2 - 1]);
+        for (int d = ND - 1; d >= 0; d--) {
+            int dig = split_digit(m, d);
+            for (int r = 0; r < 4; r++) acc = jac_dbl_ni(acc);
+            if (dig != 0) {
+                Jac<F> e = tab[(dig < 0 ? -dig : dig) - 1];
+                if (dig < 0) e.y = F::neg(e.y);
+                acc = jac_add_ni(acc, e);
+            }
+        }
+    }
+    XYZZ<F> o = XYZZ<F>::inf();
+    if (!acc.is_inf()) { o.x = acc.x; o.y = acc.y; o.zz = F::sqr(acc.z); o.zzz = F::mul(o.zz, acc.z); }
+    st(out, ec_to_affine(o));
+}
+
 extern "C" {
+// group: 0 bn254 G1, 1 bn254 G2, 2 bls G1, 3 bls G2; mag: 6 limbs
+void shim_split_mul(int group, const void* pt, const unsigned* mag, void* out) {
+    switch (group) {
+        case 0: split_mul<Fp<Bn254FqP>>(pt, mag, out); break;
+        case 1: split_mul<Fp2<Bn254FqP>>(pt, mag, out); break;
+        case 2: split_mul<Fp<Bls381FqP>>(pt, mag, out); break;
+        case 3: split_mul<Fp2<Bls381FqP>>(pt, mag, out); break;
+    }
+}
 // curve: 0 bn254, 1 bls12-381
 void shim_f12_op(int curve, int op, const void* a, const void* b, void* out) {
     if (curve == 0) f12_op<Bn254FqP>(op, a, b, out); else f12_op<Bls381FqP>(op, a, b, out);

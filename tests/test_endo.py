@@ -119,3 +119,41 @@ def test_device_side_split_recombines_and_is_short(name, tmp_path_factory):
                 assert m.bit_length() <= bits, (name, group, c, j, m.bit_length())
                 ks.append(-m if (neg >> j) & 1 else m)
             assert sum(k * pow(lam, j, r) for j, k in enumerate(ks)) % r == c % r, (name, group, c)
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_one_lane_of_the_split_kernel_multiplies_correctly(name, tmp_path_factory):
+    """csrc/endo.cuh, host-compiled: the work of ONE lane of k_points_mul_split - the table 1P .. 8P, the magnitude biased by
+    0x88..8, signed 4-bit digits, a Jacobian chain (jac_dbl_ni / jac_add_ni / jac_madd_ni) - equals the oracle's scalar
+    multiple, in G1 (parts up to 131 bits) and G2 (68 bits), for the magnitudes at the digit boundaries (0, 7, 8, 9, 15, 16,
+    0x88..8, all-ones) and random ones; infinity in, infinity out."""
+    import ctypes
+    import os
+    import subprocess
+    import numpy as np
+    from oracle.pyref.codec import Codec
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path_factory.mktemp("shim") / "field_shim.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", out,
+                           os.path.join(root, "tests", "host_shim", "field_shim.cpp")])
+    lib = ctypes.CDLL(out)
+    cp = CURVES[name]
+    cd = Codec(cp)
+    rnd = random.Random(31)
+    for group, G, gen, enc, dec, bits in ((1, curve.G1(cp), cp.g1_gen, cd.g1_vec, cd.g1_from, 131),
+                                          (2, curve.G2(cp), cp.g2_gen, cd.g2_vec, cd.g2_from, 68)):
+        gid = (0 if name == "bn254" else 2) + (group - 1)
+        P = G.mul(gen, rnd.randrange(1, cp.r))
+        pb = bytes(enc([P]))
+        mags = [0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88, 0x8888888888888888, (1 << 64) - 1, (1 << bits) - 1, 1 << (bits - 1)] + \
+               [rnd.randrange(1 << bits) for _ in range(12)]
+        for m in mags:
+            ml = np.array([(m >> (32 * i)) & 0xffffffff for i in range(6)], np.uint32)
+            got = ctypes.create_string_buffer(len(pb))
+            lib.shim_split_mul(gid, pb, ml.ctypes.data_as(ctypes.c_void_p), got)
+            have = dec(np.frombuffer(got.raw, np.uint8))
+            want = G.mul(P, m) if m % cp.r else None
+            assert (have is None and want is None) or have == (want[0], want[1]), (name, group, hex(m))
+        zero = ctypes.create_string_buffer(len(pb))
+        lib.shim_split_mul(gid, bytes(len(pb)), np.array([5, 0, 0, 0, 0, 0], np.uint32).ctypes.data_as(ctypes.c_void_p), zero)
+        assert zero.raw == bytes(len(pb))
