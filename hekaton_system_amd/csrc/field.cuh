@@ -243,6 +243,20 @@ struct Fp {
         return reduce_once(r);
     }
     HK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
+    // a / 2: (a odd ? a + p : a) >> 1 - a Montgomery value halves like its integer.  Lazy input < 2p gives < 1.5p.
+    HK_HD static Fp halve(const Fp& a) {
+        u32 odd = 0u - (a.v[0] & 1u);
+        u32 t[N];
+        u64 c = 0;
+        HK_UNROLL for (int i = 0; i < N; i++) {
+            c += (u64)a.v[i] + (P::MOD[i] & odd);
+            t[i] = (u32)c;
+            c >>= 32;
+        }
+        Fp r;
+        HK_UNROLL for (int i = 0; i < N; i++) r.v[i] = (t[i] >> 1) | ((i + 1 < N ? t[i + 1] : (u32)c) << 31);
+        return r;
+    }
     // out-of-line product with by-value (register) arguments: lets big callers (Fp2 / G2 code) keep
     // their state in registers around a compact callee instead of inlining 500 instructions per use
     HK_CALL static Fp mul_call(Fp a, Fp b) { return mul(a, b); }
@@ -273,6 +287,7 @@ struct Fp2 {
     HK_HD static Fp2 add(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = B::add(a.c0, b.c0); r.c1 = B::add(a.c1, b.c1); return r; }
     HK_HD static Fp2 sub(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = B::sub(a.c0, b.c0); r.c1 = B::sub(a.c1, b.c1); return r; }
     HK_HD static Fp2 dbl(const Fp2& a) { return add(a, a); }
+    HK_HD static Fp2 halve(const Fp2& a) { Fp2 r; r.c0 = B::halve(a.c0); r.c1 = B::halve(a.c1); return r; }
     HK_HD static Fp2 neg(const Fp2& a) { Fp2 r; r.c0 = B::neg(a.c0); r.c1 = B::neg(a.c1); return r; }
     // base-field product used by the extension: inline (asm block) for 8-limb fields, an out-of-line
     // call with register arguments for 12-limb fields (keeps BLS12-381 code size and scratch small)

@@ -25,12 +25,21 @@ template <class P>
 HK_RARE LineCoeffs<P> pair_doubling_step(G2Proj<P>& r) {
     typedef Fp2<P> F;
     typedef TowerParams<P> T;
-    Fp<P> two_inv = fp_const<P>(T::TWO_INV);
-    F a = f2_scale(f2m(r.x, r.y), two_inv);
+    // the two divisions by 2 are halvings (add p if odd, shift), not products by 1/2: 4 of the step's 28 base-field products
+    F a = F::halve(f2m(r.x, r.y));
     F b = f2s(r.y), c = f2s(r.z);
-    F e = f2m(fp2_const<P>(T::B_TWIST), F::add(F::add(c, c), c));
+    F c3 = F::add(F::add(c, c), c);
+    F e;
+    if constexpr (T::B_TWIST_IS_4_4) {                       // b' = 4 (1 + i): (u + v i) b' = 4 (u - v) + 4 (u + v) i
+        F t;
+        t.c0 = Fp<P>::sub(c3.c0, c3.c1);
+        t.c1 = Fp<P>::add(c3.c0, c3.c1);
+        e = F::dbl(F::dbl(t));
+    } else {
+        e = f2m(fp2_const<P>(T::B_TWIST), c3);
+    }
     F f = F::add(F::add(e, e), e);
-    F g = f2_scale(F::add(b, f), two_inv);
+    F g = F::halve(F::add(b, f));
     F h = F::sub(f2s(F::add(r.y, r.z)), F::add(b, c));
     F i = F::sub(e, b);
     F j = f2s(r.x);

@@ -23,6 +23,7 @@ template <class P> struct TowerParams;
         static constexpr int LOOP_LEN = PRE##_LOOP_LEN;                                                 \
         static constexpr u32 TWO_INV[FQP::N] = PRE##_TWO_INV;                                           \
         static constexpr u32 B_TWIST[2][FQP::N] = PRE##_B_TWIST;                                        \
+        static constexpr bool B_TWIST_IS_4_4 = PRE##_B_TWIST_IS_4_4 != 0;                               \
         static constexpr u32 FROB6_C1[3][2][FQP::N] = {PRE##_FROB6_C1_1, PRE##_FROB6_C1_2, PRE##_FROB6_C1_3};    \
         static constexpr u32 FROB6_C2[3][2][FQP::N] = {PRE##_FROB6_C2_1, PRE##_FROB6_C2_2, PRE##_FROB6_C2_3};    \
         static constexpr u32 FROB12_C1[3][2][FQP::N] = {PRE##_FROB12_C1_1, PRE##_FROB12_C1_2, PRE##_FROB12_C1_3}; \
