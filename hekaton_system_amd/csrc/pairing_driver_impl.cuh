@@ -17,8 +17,15 @@ template <class P>
 hk_status PairRun<P>::gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out) {
     typedef typename ScalarOfQ<P>::type Fr;
     if (n == 0) return HK_OK;
-    size_t lds = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
-    hipLaunchKernelGGL((k_gt_pow<P, Fr>), dim3(n), dim3(64), lds, s, in, (const Fr*)scalars_mont, n, out);
+    const bool plain = getenv("HK_GT_POW_PLAIN") != nullptr;        // the 254-step chain (A/B; any Fq12 element, not only GT)
+    if (plain) {
+        size_t lds = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
+        hipLaunchKernelGGL((k_gt_pow<P, Fr>), dim3(n), dim3(64), lds, s, in, (const Fr*)scalars_mont, n, out);
+    } else {
+        static const EndoSplit<4> E = endo_split_g2((const P*)nullptr);
+        size_t lds = sizeof(WaveArea<P>) + 16 * WV_SLOT * sizeof(Fp<P>);
+        hipLaunchKernelGGL((k_gt_pow_endo<P, Fr>), dim3(n), dim3(64), lds, s, in, (const Fr*)scalars_mont, n, E, out);
+    }
     HK_DBG(s, "k_gt_pow");
     HK_HIP(hipGetLastError());
     return HK_OK;
@@ -28,7 +35,7 @@ template <class P>
 size_t PairRun<P>::max_private_bytes() {
     const void* ks[] = {(const void*)k_pair_lines<P>, (const void*)k_pair_tree_lines<P>, (const void*)k_pair_tree<P>,
                         (const void*)k_pair_horner<P>,
-                        (const void*)k_gt_pow<P, typename ScalarOfQ<P>::type>};
+                        (const void*)k_gt_pow<P, typename ScalarOfQ<P>::type>, (const void*)k_gt_pow_endo<P, typename ScalarOfQ<P>::type>};
     const void* serial[] = {(const void*)k_pair_miller<P>, (const void*)k_f12_product<P>, (const void*)k_final_exp<P>};
     size_t m = 0;
     for (const void* k : ks) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }

@@ -185,7 +185,9 @@ hk_status hk_pairing_pairs(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs,
 hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt);
 /* gt_out[i] = gt_in[i]^scalars[i] in GT - `Commitment * scalar` (distributed-prover/src/aggregation.rs:171-174,328-332) and
  * the six GT powers per round of the TIPA verifier; one wavefront per element.  gt_in, gt_out [h|d]: n GT elements;
- * scalars_mont [h|d]: n Fr. */
+ * scalars_mont [h|d]: n Fr.  The inputs must lie IN GT (order r: pairing values and their products - what `PairingOutput`
+ * holds): the exponent is split along the Frobenius, z^c = prod_j pi^j(z)^(k_j) with four parts of <= 67 bits, which is
+ * z^c only there.  (HK_GT_POW_PLAIN in the environment selects the plain 254-step chain, valid for any Fq12 element.) */
 hk_status hk_gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, size_t n, void* gt_out);
 
 /* Element-wise linear combination of k <= 8 point vectors: out[i] = sum_j coeffs[j] * vecs[j][i], batch-normalised to

@@ -86,19 +86,32 @@ def test_multi_pairing_1024_bilinearity_and_cross_terms(ctx_bn254):
 
 
 @pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
-def test_gt_pow_matches_the_oracle(cname, ctx_bn254, ctx_bls):
-    """hk_gt_pow (one wavefront per element, square-and-multiply on the wave multiplier) against the tower oracle,
-    including exponents 0, 1 and r - 1 and a generic Fq12 base."""
+def test_gt_pow_matches_the_oracle(cname, ctx_bn254, ctx_bls, monkeypatch):
+    """hk_gt_pow (one wavefront per element on the wave multiplier) against the tower oracle: the default form splits the
+    exponent along the Frobenius (GT elements only: pi(z) = z^q, four parts <= 67 bits, one joint chain) - exponents 0, 1,
+    r - 1, the eigenvalue and its negative, 2^64, random; the plain 254-step chain (HK_GT_POW_PLAIN) also on a generic
+    Fq12 base."""
     ctx = _ctx(cname, ctx_bn254, ctx_bls)
     cp = CURVES[cname]
     T = pairing.tower(cname)
     E = Enc(cp)
     from hekaton_system_amd.cp_groth16 import FrCodec
+    from hekaton_system_amd.endo import psi4
     fc = FrCodec(cname)
     rnd = random.Random(21)
     g = T.pairing(cp.g1_gen, cp.g2_gen)
-    bases = [g, g, g, T.f12_from_flat([rnd.randrange(cp.q) for _ in range(12)]), T.f12_pow(g, 12345)]
-    exps = [0, 1, cp.r - 1, rnd.randrange(cp.r), rnd.randrange(cp.r)]
-    out = ctx.gt_pow(np.frombuffer(b"".join(E.f12(T.f12_flat(b)) for b in bases), np.uint8), fc.enc(exps))
+    h = T.f12_pow(g, 12345)
+    lam = psi4(cname).lam
+    exps = [0, 1, cp.r - 1, lam, cp.r - lam, lam * lam % cp.r, 1 << 64, (1 << 128) - 1] + [rnd.randrange(cp.r) for _ in range(6)]
+    bases = [g if k % 2 == 0 else h for k in range(len(exps))]
+    enc = lambda bs: np.frombuffer(b"".join(E.f12(T.f12_flat(b)) for b in bs), np.uint8)
+    out = ctx.gt_pow(enc(bases), fc.enc(exps))
     for k, (b, e) in enumerate(zip(bases, exps)):
         assert E.f12_dec(out[k].tobytes()) == T.f12_flat(T.f12_pow(b, e)), k
+    monkeypatch.setenv("HK_GT_POW_PLAIN", "1")
+    bases2 = [g, T.f12_from_flat([rnd.randrange(cp.q) for _ in range(12)]), h]
+    exps2 = [cp.r - 1, rnd.randrange(cp.r), rnd.randrange(cp.r)]
+    out2 = ctx.gt_pow(enc(bases2), fc.enc(exps2))
+    for k, (b, e) in enumerate(zip(bases2, exps2)):
+        assert E.f12_dec(out2[k].tobytes()) == T.f12_flat(T.f12_pow(b, e)), ("plain", k)
+    assert np.array_equal(out2[0], out[2])

@@ -131,6 +131,14 @@ def main():
         T = tipa.Tipp(ctx, curve)
         vk = tipa.verifier_key(ctx, curve, srs)
         apk.agg_subcircuit_proofs(Merlin(b"bench"), super_com, proofs, pub, srs, tipp=T)          # warm
+        if os.environ.get("HK_AGG_CPROFILE"):                 # where the HOST time of the front half and the verifier goes
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            inst_ = apk.agg_front(super_com, proofs, pub, pt=Merlin(b"bench"))
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
         t0 = time.time()
         inst = apk.agg_front(super_com, proofs, pub, pt=Merlin(b"bench"))
         t1 = time.time()
