@@ -180,3 +180,26 @@ def test_folds_that_share_a_scalar_in_one_call(cname, group, ctx_bn254, ctx_bls)
     for y in range(3):
         assert np.array_equal(np.frombuffer(dev[y].to_host(), np.uint8), want[y]), (cname, group, y, "device out")
         dev[y].free()
+
+
+def test_the_longest_vector_of_the_k_lane_form(ctx_bn254, monkeypatch):
+    """n K = 65 536 lanes exactly (G2: n = 16 384; G1: n = 32 768) is the last size k_points_mul_split takes; one element
+    more goes to the one-lane kernels.  Both sizes, both groups: the same bytes as the one-lane form, for the fold and for
+    `scalar_pairing`."""
+    ctx = ctx_bn254
+    cp, fc, cd = CURVES["bn254"], FrCodec("bn254"), Codec(CURVES["bn254"])
+    rnd = random.Random(41)
+    for group, n_edge in ((2, 16384), (1, 32768)):
+        gen = cp.g1_gen if group == 1 else cp.g2_gen
+        vec = (cd.g1_vec if group == 1 else cd.g2_vec)([gen])
+        fold = ctx.points_fold_g1 if group == 1 else ctx.points_fold_g2
+        for n in (n_edge, n_edge + 1):
+            hi = ctx.fixed_base(group, vec, fc.enc([rnd.randrange(1, cp.r) for _ in range(n)])).copy()
+            lo = ctx.fixed_base(group, vec, fc.enc([rnd.randrange(1, cp.r) for _ in range(n)])).copy()
+            scal = fc.enc([rnd.randrange(cp.r) for _ in range(n)])
+            c = rnd.randrange(cp.r)
+            monkeypatch.delenv("HK_ENDO_ONE_LANE", raising=False)
+            a = (fold(lo, hi, c, n=n).copy(), ctx.scalar_pairing(group, hi, scal, n=n).copy())
+            monkeypatch.setenv("HK_ENDO_ONE_LANE", "1")
+            b = (fold(lo, hi, c, n=n).copy(), ctx.scalar_pairing(group, hi, scal, n=n).copy())
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (group, n)
