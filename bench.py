@@ -324,15 +324,31 @@ class Job:
         from hekaton_system_amd.sha_circuit import full_values, poseidon_inputs
         t0 = time.time()
 
-        def one(c):
+        trace = bool(os.environ.get("HK_WG_TRACE"))
+
+        def program(c):
             circ = c["circ"]
+            ta = time.time()
             cols, vals = full_values(circ, c["wg_ws"])
+            tb = time.time()
             c["wprog"].run(c["wg_inputs"], cols, vals, out=c["zbig"])
+            if trace:
+                log("witness gen, class of %d: host full values %.1f ms, word program + expansion %.1f"
+                    % (len(c["wg_ws"]), (tb - ta) * 1e3, (time.time() - tb) * 1e3))
+
+        def membership(c):
             # the membership block (execution-tree leaf hash + path, subcircuit_circuit.rs:233-252) from the request's
-            # leaf and path, computed on the device into the same assignments
+            # leaf and path, computed on the device into its own columns of the same assignments - beside the program
+            circ = c["circ"]
+            ta = time.time()
             leaves, sibs, idx = poseidon_inputs(circ, c["wg_ws"])
             self.ctx.poseidon_path(self.poseidon_params, leaves, sibs, idx, circ.n_v, circ.pos_col0, c["zbig"])
-        list(self.pool.map(one, list(self.classes.values())))
+            if trace:
+                log("witness gen, class of %d: poseidon path %.1f ms" % (len(c["wg_ws"]), (time.time() - ta) * 1e3))
+
+        def one(job):
+            job[0](job[1])
+        list(self.pool.map(one, [(f, c) for c in self.classes.values() for f in (program, membership)]))
         return time.time() - t0
 
     def _gather(self, records):

@@ -20,8 +20,18 @@ enum { WOP_INPUT = 0, WOP_CONST, WOP_XOR, WOP_CH, WOP_AND, WOP_MAJ, WOP_ADD, WOP
 
 #if defined(__HIPCC__)
 
-__device__ __forceinline__ u32 wp_ref(const u32* __restrict__ values, u32 ref, u32 batch, u32 lane) {
-    u32 v = values[(size_t)(ref & 0xfffffu) * batch + lane];
+// The program is one dependent chain per lane (a SHA-256 round needs the previous round's words), and every link was a
+// global store followed by a global load of the same word: ~1.2 us per op.  The last WP_RING values of a lane therefore
+// also live in LDS ([slot][lane], conflict-free); a reference reaches back at most ~200 values inside a compression
+// (W[t-16]), so nearly every operand comes from there.  Every value still goes to `values` for k_witness_expand.
+constexpr u32 WP_RING = 256;
+
+__device__ __forceinline__ u32 wp_word(const u32* __restrict__ values, const u32* ring, u32 id, u32 vid, u32 batch, u32 lane) {
+    if (vid - id <= WP_RING) return ring[(id & (WP_RING - 1)) * 64 + threadIdx.x];
+    return values[(size_t)id * batch + lane];
+}
+__device__ __forceinline__ u32 wp_ref(const u32* __restrict__ values, const u32* ring, u32 ref, u32 vid, u32 batch, u32 lane) {
+    u32 v = wp_word(values, ring, ref & 0xfffffu, vid, batch, lane);
     u32 rot = (ref >> 20) & 31u, shr = (ref >> 25) & 31u;
     if (shr) return v >> shr;
     return rot ? ((v >> rot) | (v << (32u - rot))) : v;
@@ -32,44 +42,57 @@ template <int UNUSED>
 __global__ void __launch_bounds__(64)
 k_word_program(const u32* __restrict__ ops, u32 n_ops, const u32* __restrict__ refs, const u32* __restrict__ inputs,
                u32 n_inputs, u32 batch, u32* __restrict__ values) {
+    __shared__ u32 ring[WP_RING * 64];
     u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= batch) return;
     u32 vid = 0;
+    auto put = [&](u32 r) {
+        ring[(vid & (WP_RING - 1)) * 64 + threadIdx.x] = r;
+        values[(size_t)vid * batch + lane] = r;
+        vid++;
+    };
+    // the op stream is the same for every lane (scalar loads); op k + 1 is requested before op k executes
+    uint4 o_next = reinterpret_cast<const uint4*>(ops)[0];
+    u32 imm_next = ops[4];
     for (u32 k = 0; k < n_ops; k++) {
-        const uint4 o = reinterpret_cast<const uint4*>(ops)[2 * k];
-        u32 imm = ops[8 * k + 4];
+        const uint4 o = o_next;
+        const u32 imm = imm_next;
+        if (k + 1 < n_ops) {
+            o_next = reinterpret_cast<const uint4*>(ops)[2 * (k + 1)];
+            imm_next = ops[8 * (k + 1) + 4];
+        }
         u32 r;
         switch (o.x) {
             case WOP_INPUT: r = inputs[(size_t)lane * n_inputs + imm]; break;
             case WOP_CONST: r = imm; break;
-            case WOP_XOR: r = wp_ref(values, o.y, batch, lane) ^ wp_ref(values, o.z, batch, lane); break;
+            case WOP_XOR: r = wp_ref(values, ring, o.y, vid, batch, lane) ^ wp_ref(values, ring, o.z, vid, batch, lane); break;
             case WOP_CH: {
-                u32 e = wp_ref(values, o.y, batch, lane), f = wp_ref(values, o.z, batch, lane), g = wp_ref(values, o.w, batch, lane);
+                u32 e = wp_ref(values, ring, o.y, vid, batch, lane), f = wp_ref(values, ring, o.z, vid, batch, lane),
+                    g = wp_ref(values, ring, o.w, vid, batch, lane);
                 r = (e & f) ^ (~e & g);
                 break;
             }
-            case WOP_AND: r = wp_ref(values, o.y, batch, lane) & wp_ref(values, o.z, batch, lane); break;
+            case WOP_AND: r = wp_ref(values, ring, o.y, vid, batch, lane) & wp_ref(values, ring, o.z, vid, batch, lane); break;
             case WOP_MAJ: {
-                u32 x = wp_ref(values, o.y, batch, lane), y = wp_ref(values, o.z, batch, lane), z = wp_ref(values, o.w, batch, lane);
+                u32 x = wp_ref(values, ring, o.y, vid, batch, lane), y = wp_ref(values, ring, o.z, vid, batch, lane),
+                    z = wp_ref(values, ring, o.w, vid, batch, lane);
                 r = (x & y) ^ (x & z) ^ (y & z);
                 break;
             }
             case WOP_ADD: {
                 u64 tot = imm;
-                for (u32 j = 0; j < o.z; j++) tot += wp_ref(values, refs[o.y + j], batch, lane);
-                values[(size_t)vid * batch + lane] = (u32)tot;
-                vid++;
+                for (u32 j = 0; j < o.z; j++) tot += wp_ref(values, ring, refs[o.y + j], vid, batch, lane);
+                put((u32)tot);
                 r = (u32)(tot >> 32);
                 break;
             }
             default: {   // WOP_PACK4
-                u32 p0 = values[(size_t)(refs[o.y] & 0xfffffu) * batch + lane], p1 = values[(size_t)(refs[o.y + 1] & 0xfffffu) * batch + lane];
-                u32 p2 = values[(size_t)(refs[o.y + 2] & 0xfffffu) * batch + lane], p3 = values[(size_t)(refs[o.y + 3] & 0xfffffu) * batch + lane];
+                u32 p0 = wp_word(values, ring, refs[o.y] & 0xfffffu, vid, batch, lane), p1 = wp_word(values, ring, refs[o.y + 1] & 0xfffffu, vid, batch, lane);
+                u32 p2 = wp_word(values, ring, refs[o.y + 2] & 0xfffffu, vid, batch, lane), p3 = wp_word(values, ring, refs[o.y + 3] & 0xfffffu, vid, batch, lane);
                 r = (p0 << 24) | (p1 << 16) | (p2 << 8) | p3 | imm;
             }
         }
-        values[(size_t)vid * batch + lane] = r;
-        vid++;
+        put(r);
     }
 }
 
