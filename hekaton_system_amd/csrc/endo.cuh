@@ -276,7 +276,7 @@ HK_RARE Jac<F> jac_madd_ni(const Jac<F>& p, const Affine<F>& q) {
     return r;
 }
 
-constexpr u32 SPLIT_MAX_LANES = 65536;           // n K up to one wave on every SIMD of the chip
+constexpr u32 SPLIT_MAX_LANES = 65536;           // n K (x 4 in the quad form) up to one wave on every SIMD of the chip
 constexpr int SPLIT_TABLE = 8;                   // 1P .. 8P
 
 // bytes of the table scratch of k_points_mul_split for n elements
@@ -305,10 +305,93 @@ HK_HD int split_digit(const u32 (&m)[6], int d) { return (int)((m[d >> 3] >> (4 
 template <class F> struct SplitDigits { static constexpr int ND = (EndoOf<F>::STEPS + 3) / 4 + 1; };
 
 #if defined(__HIPCC__)
+// ---- Fq2 on FOUR lanes -------------------------------------------------------------------------------------------------
+// The lanes of a quad (4 t .. 4 t + 3) hold the SAME Fq2 value; a product is ONE base-field product per lane - lane 0:
+// a0 b0, lane 1: a1 b1, lanes 2, 3: (a0 + a1)(b0 + b1) - quad-broadcast (DPP quad_perm, 3 N moves) and recombined by every
+// lane: the 3 (product) / 2 (square) sequential base-field products of Fq2 become one.  Additions run redundantly.  Same
+// memory layout as Fp2<P>; every control decision depends on values all four lanes share, so a quad never diverges.
+// Only for chains whose time is one lane's latency (few hundred elements): total work is 4 / 1.7 times the one-lane form's.
+template <class P>
+struct Fp2Q {
+    typedef Fp<P> B;
+    typedef P Params;
+    static constexpr int N = 2 * P::N;
+    B c0, c1;
+
+    __device__ __forceinline__ static Fp2Q zero() { Fp2Q r; r.c0 = B::zero(); r.c1 = B::zero(); return r; }
+    __device__ __forceinline__ static Fp2Q one() { Fp2Q r; r.c0 = B::one(); r.c1 = B::zero(); return r; }
+    __device__ __forceinline__ bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    __device__ __forceinline__ static Fp2Q canon(const Fp2Q& a) { Fp2Q r; r.c0 = B::canon(a.c0); r.c1 = B::canon(a.c1); return r; }
+    __device__ __forceinline__ static Fp2Q add(const Fp2Q& a, const Fp2Q& b) { Fp2Q r; r.c0 = B::add(a.c0, b.c0); r.c1 = B::add(a.c1, b.c1); return r; }
+    __device__ __forceinline__ static Fp2Q sub(const Fp2Q& a, const Fp2Q& b) { Fp2Q r; r.c0 = B::sub(a.c0, b.c0); r.c1 = B::sub(a.c1, b.c1); return r; }
+    __device__ __forceinline__ static Fp2Q dbl(const Fp2Q& a) { return add(a, a); }
+    __device__ __forceinline__ static Fp2Q neg(const Fp2Q& a) { Fp2Q r; r.c0 = B::neg(a.c0); r.c1 = B::neg(a.c1); return r; }
+    __device__ __forceinline__ static Fp2Q conj(const Fp2Q& a) { Fp2Q r; r.c0 = a.c0; r.c1 = B::neg(a.c1); return r; }
+    template <int CTRL>
+    __device__ __forceinline__ static B quad_bcast(const B& v) {
+        B r;
+        HK_UNROLL for (int i = 0; i < P::N; i++)
+            r.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)v.v[i], CTRL, 0xf, 0xf, true);
+        return r;
+    }
+    __device__ __forceinline__ static B pick(u32 role, const B& r0, const B& r1, const B& r2) {
+        B r;
+        HK_UNROLL for (int i = 0; i < P::N; i++) r.v[i] = role == 0 ? r0.v[i] : role == 1 ? r1.v[i] : r2.v[i];
+        return r;
+    }
+    __device__ __forceinline__ static Fp2Q mul(const Fp2Q& a, const Fp2Q& b) {
+        u32 role = threadIdx.x & 3u;
+        B x = pick(role, a.c0, a.c1, B::add(a.c0, a.c1));
+        B y = pick(role, b.c0, b.c1, B::add(b.c0, b.c1));
+        B v = B::mul(x, y);
+        B v0 = quad_bcast<0x00>(v), v1 = quad_bcast<0x55>(v), v2 = quad_bcast<0xAA>(v);
+        Fp2Q r;
+        r.c0 = B::sub(v0, v1);
+        r.c1 = B::sub(B::sub(v2, v0), v1);
+        return r;
+    }
+    __device__ __forceinline__ static Fp2Q sqr(const Fp2Q& a) {       // lanes 0, 2: (a0 + a1)(a0 - a1); lanes 1, 3: a0 a1
+        bool odd = threadIdx.x & 1u;
+        B s = B::add(a.c0, a.c1), d = B::sub(a.c0, a.c1);
+        B x = pick(odd ? 1u : 0u, s, a.c0, s);
+        B y = pick(odd ? 1u : 0u, d, a.c1, d);
+        B v = B::mul(x, y);
+        Fp2Q r;
+        r.c0 = quad_bcast<0x00>(v);
+        r.c1 = B::dbl(quad_bcast<0x55>(v));
+        return r;
+    }
+};
+template <class P>
+__device__ __forceinline__ void st_vec(Fp2Q<P>* p, const Fp2Q<P>& v) {
+    st_vec(&p->c0, v.c0);
+    st_vec(&p->c1, v.c1);
+}
+template <class P> struct EndoOf<Fp2Q<P>> {
+    static constexpr int K = 4, STEPS = 68;
+    __device__ static Affine<Fp2Q<P>> apply(const Affine<Fp2Q<P>>& q) {          // g2_psi (pairing.cuh) on quad values
+        typedef TowerParams<P> T;
+        typedef Fp2Q<P> F;
+        F kx, ky;
+        HK_UNROLL for (int i = 0; i < P::N; i++) {
+            kx.c0.v[i] = T::PSI_X[0][i]; kx.c1.v[i] = T::PSI_X[1][i];
+            ky.c0.v[i] = T::PSI_Y[0][i]; ky.c1.v[i] = T::PSI_Y[1][i];
+        }
+        Affine<F> r;
+        r.x = F::mul(F::conj(q.x), kx);
+        r.y = F::mul(F::conj(q.y), ky);
+        return r;
+    }
+};
+// lanes that carry one value of the field: 1, or 4 for the quad form
+template <class F> struct LanesPerValue { static constexpr int value = 1; };
+template <class P> struct LanesPerValue<Fp2Q<P>> { static constexpr int value = 4; };
+
 // out[i] = (lo ? lo[i] : 0) + s_i * pts[i].   UNIFORM: one scalar for the whole vector, split on the host: `scalars` = K
 // Montgomery magnitudes, neg_all = their sign mask (the fold of a TIPA round);  else scalars[i], split here by every lane
 // of the element (the split is ~300 integer products: cheaper than passing it between lanes).
-// grid: (ceil(n K / 64), vectors) blocks of 64 lanes; lane t: element t / K, part t % K; vector y = blockIdx.y reads
+// grid: (ceil(n K L / 64), vectors) blocks of 64 lanes (L = 1, or 4 with the quad field Fp2Q: t counts quads); lane / quad t:
+// element t / K, part t % K; vector y = blockIdx.y reads
 // v.lo[y] / v.pts[y] and writes out[y n ..) (UNIFORM: the same scalar for every vector - the folds of one TIPA round).
 // tab: vectors x split_tab_bytes(n).
 constexpr int FOLD_MAX = 4;
@@ -320,10 +403,12 @@ k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, 
                    Jac<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
     constexpr int K = EndoOf<F>::K;
     constexpr int ND = SplitDigits<F>::ND;                        // nibbles of m'
-    __shared__ Jac<F> sh[64];
+    constexpr int L = LanesPerValue<F>::value;                    // 4: every value on a quad of lanes (Fp2Q), t = the quad
+    __shared__ Jac<F> sh[64 / L];
     const Affine<F>* __restrict__ lo = v.lo[blockIdx.y];
     const Affine<F>* __restrict__ pts = v.pts[blockIdx.y];
-    u32 t = blockIdx.x * 64 + threadIdx.x;
+    const u32 tl = threadIdx.x / L;
+    u32 t = blockIdx.x * (64 / L) + tl;
     u32 i = t / K, j = t % K;
     bool valid = i < n;
     size_t lanes = (size_t)n * K;
@@ -378,10 +463,10 @@ k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, 
             }
         }
     }
-    sh[threadIdx.x] = acc;
+    sh[tl] = acc;
     __syncthreads();
     if (valid && j == 0) {
-        HK_NOUNROLL for (int k = 1; k < K; k++) acc = jac_add_ni(acc, sh[threadIdx.x + k]);
+        HK_NOUNROLL for (int k = 1; k < K; k++) acc = jac_add_ni(acc, sh[tl + k]);
         XYZZ<F> o = XYZZ<F>::inf();
         if (!acc.is_inf()) {
             o.x = acc.x; o.y = acc.y;

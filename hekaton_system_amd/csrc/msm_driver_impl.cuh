@@ -166,6 +166,30 @@ hk_status MsmRun<F>::batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* o
     return HK_OK;
 }
 
+// the K-lane sweep (endo.cuh): for G2 with few elements every Fq2 value on a quad of lanes (Fp2Q), else one lane per value
+template <class Fr, class P, bool UNIFORM>
+static inline void launch_mul_split(hipStream_t s, const SplitVecs<Fp2<P>>& v, u32 k, const Fr* scalars, u32 neg_mask, u32 n,
+                                    const EndoSplit<4>& E, Jac<Fp2<P>>* tab, XYZZ<Fp2<P>>* xy) {
+    const bool no_quad = getenv("HK_ENDO_NO_QUAD") != nullptr;
+    u32 lanes = n * 4;
+    if (!no_quad && (size_t)lanes * 4 <= SPLIT_MAX_LANES) {
+        typedef Fp2Q<P> Q;                                    // same memory layout as Fp2<P>
+        SplitVecs<Q> vq;
+        for (int y = 0; y < FOLD_MAX; y++) { vq.lo[y] = (const Affine<Q>*)v.lo[y]; vq.pts[y] = (const Affine<Q>*)v.pts[y]; }
+        hipLaunchKernelGGL((k_points_mul_split<Fr, Q, UNIFORM>), dim3((lanes * 4 + 63) / 64, k), dim3(64), 0, s, vq, scalars,
+                           neg_mask, n, E, (Jac<Q>*)tab, (XYZZ<Q>*)xy);
+    } else {
+        hipLaunchKernelGGL((k_points_mul_split<Fr, Fp2<P>, UNIFORM>), dim3((lanes + 63) / 64, k), dim3(64), 0, s, v, scalars,
+                           neg_mask, n, E, tab, xy);
+    }
+}
+template <class Fr, class P, bool UNIFORM>
+static inline void launch_mul_split(hipStream_t s, const SplitVecs<Fp<P>>& v, u32 k, const Fr* scalars, u32 neg_mask, u32 n,
+                                    const EndoSplit<2>& E, Jac<Fp<P>>* tab, XYZZ<Fp<P>>* xy) {
+    hipLaunchKernelGGL((k_points_mul_split<Fr, Fp<P>, UNIFORM>), dim3((n * 2 + 63) / 64, k), dim3(64), 0, s, v, scalars,
+                       neg_mask, n, E, tab, xy);
+}
+
 template <class F>
 hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const void* scalars_mont, u32 n,
                                      XYZZ<F>* xy, F* pref, Affine<F>* out, XYZZ<F>* tab) {
@@ -176,11 +200,9 @@ hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const 
     if (tab && !plain && !one_lane && (size_t)n * EndoOf<F>::K <= SPLIT_MAX_LANES) {
         // short vector: K lanes per element, 4-bit windows, Jacobian chain (endo.cuh)
         static const auto E = EndoOf<F>::split();
-        u32 lanes = n * EndoOf<F>::K;
         SplitVecs<F> v = {};
         v.pts[0] = pts;
-        hipLaunchKernelGGL((k_points_mul_split<Fr, F, false>), dim3((lanes + 63) / 64), dim3(64), 0, s, v,
-                           (const Fr*)scalars_mont, 0u, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
+        launch_mul_split<Fr, typename F::Params, false>(s, v, 1u, (const Fr*)scalars_mont, 0u, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
     } else if (tab && !plain) {
         // scalars split on the device along phi / psi: one shared chain of 131 (G1) / 68 (G2) doublings (endo.cuh)
         static const auto E = EndoOf<F>::split();
@@ -203,11 +225,9 @@ hk_status MsmRun<F>::fold_endo(hipStream_t s, u32 k, const Affine<F>* const* lo,
     const bool one_lane = getenv("HK_ENDO_ONE_LANE") != nullptr;
     if (!one_lane && (size_t)n * EndoOf<F>::K <= SPLIT_MAX_LANES) {
         static const auto E = EndoOf<F>::split();                                // unused by the uniform form
-        u32 lanes = n * EndoOf<F>::K;
         SplitVecs<F> v = {};
         for (u32 y = 0; y < k; y++) { v.lo[y] = lo[y]; v.pts[y] = hi[y]; }
-        hipLaunchKernelGGL((k_points_mul_split<Fr, F, true>), dim3((lanes + 63) / 64, k), dim3(64), 0, s, v,
-                           (const Fr*)coeffs_mont, neg_mask, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
+        launch_mul_split<Fr, typename F::Params, true>(s, v, k, (const Fr*)coeffs_mont, neg_mask, n, E, reinterpret_cast<Jac<F>*>(tab), xy);
     } else {
         for (u32 y = 0; y < k; y++)                                              // long vectors: throughput-bound, one after the other
             hipLaunchKernelGGL((k_points_fold_endo<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, lo[y], hi[y], (const Fr*)coeffs_mont,
