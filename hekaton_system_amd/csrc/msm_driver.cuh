@@ -91,7 +91,8 @@ struct PairRun {
     static size_t max_private_bytes();   // as MsmRun<F>::max_private_bytes, over the pairing / endomorphism kernels
     static u32 steps();          // line-evaluation steps of the Miller loop (the factor of `count` in the tree launches' grid.y)
     // out[e] = in[e]^scalars[e] (GT powers; device pointers)
-    static hk_status gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out);
+    // in_gt: the elements lie in GT (order r) - the exponent is then split along the Frobenius (k_gt_pow_endo)
+    static hk_status gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out, bool in_gt);
 };
 
 }  // namespace hk

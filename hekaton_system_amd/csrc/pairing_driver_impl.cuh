@@ -14,10 +14,10 @@ template <> struct ScalarOfQ<Bn254FqP> { typedef Fp<Bn254FrP> type; };
 template <> struct ScalarOfQ<Bls381FqP> { typedef Fp<Bls381FrP> type; };
 
 template <class P>
-hk_status PairRun<P>::gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out) {
+hk_status PairRun<P>::gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out, bool in_gt) {
     typedef typename ScalarOfQ<P>::type Fr;
     if (n == 0) return HK_OK;
-    const bool plain = getenv("HK_GT_POW_PLAIN") != nullptr;        // the 254-step chain (A/B; any Fq12 element, not only GT)
+    const bool plain = !in_gt || getenv("HK_GT_POW_PLAIN") != nullptr;   // the 254-step chain: any Fq12 element (or A/B)
     if (plain) {
         size_t lds = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
         hipLaunchKernelGGL((k_gt_pow<P, Fr>), dim3(n), dim3(64), lds, s, in, (const Fr*)scalars_mont, n, out);

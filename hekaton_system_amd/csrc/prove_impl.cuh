@@ -1159,7 +1159,7 @@ hk_status Ops<C>::pairing_pairs(hk_ctx* ctx, const void* const* lhs, size_t n_lh
 }
 
 template <class C>
-hk_status Ops<C>::gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars, size_t n, void* gt_out) {
+hk_status Ops<C>::gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars, size_t n, void* gt_out, int in_gt) {
     typedef typename Fq::Params P;
     typedef Fp12<P> GT;
     if (n == 0) return HK_OK;
@@ -1174,7 +1174,7 @@ hk_status Ops<C>::gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars, si
     bool out_dev = is_device_ptr(gt_out);
     GT* od = out_dev ? (GT*)gt_out : L->alloc_n<GT>(n);
     if (!od) return HK_ERR_NOMEM;
-    HK_TRY(PairRun<P>::gt_pow(L->stream, (const GT*)ind, sd, (u32)n, od));
+    HK_TRY(PairRun<P>::gt_pow(L->stream, (const GT*)ind, sd, (u32)n, od, in_gt != 0));
     if (!out_dev) HK_HIP(hipMemcpyAsync(gt_out, od, n * sizeof(GT), hipMemcpyDeviceToHost, L->stream));
     HK_HIP(hipStreamSynchronize(L->stream));
     return HK_OK;

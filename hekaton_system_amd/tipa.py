@@ -252,7 +252,9 @@ class Tipp:
             bases += [rd["TL"], rd["UL"], rd["ZL"], rd["TR"], rd["UR"], rd["ZR"]]
             exps += [c, c, c, c_inv, c_inv, c_inv]
         if bases:
-            pw = ctx.gt_pow(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), fc.enc(exps))
+            # the proof's GT members are the prover's word: the plain chain (hk_fq12_pow), not the Frobenius split that is
+            # only a power for elements of order r
+            pw = ctx.gt_pow(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), fc.enc(exps), in_gt=False)
             for k in range(0, len(bases), 6):
                 tl, ul, zl, trr, ur, zr = (F.decode(pw[k + j]) for j in range(6))
                 T = F.mul(F.mul(tl, T), trr)

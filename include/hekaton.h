@@ -187,8 +187,11 @@ hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt);
  * the six GT powers per round of the TIPA verifier; one wavefront per element.  gt_in, gt_out [h|d]: n GT elements;
  * scalars_mont [h|d]: n Fr.  The inputs must lie IN GT (order r: pairing values and their products - what `PairingOutput`
  * holds): the exponent is split along the Frobenius, z^c = prod_j pi^j(z)^(k_j) with four parts of <= 67 bits, which is
- * z^c only there.  (HK_GT_POW_PLAIN in the environment selects the plain 254-step chain, valid for any Fq12 element.) */
+ * z^c only there (hk_fq12_pow below takes any element; HK_GT_POW_PLAIN in the environment routes hk_gt_pow to it). */
 hk_status hk_gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, size_t n, void* gt_out);
+/* The same power for ANY Fq12 elements (the plain 254-step square-and-multiply chain): what a verifier uses on values it
+ * has not produced itself - the GT members of a TIPA proof (ark's `PairingOutput` deserialises without a subgroup check). */
+hk_status hk_fq12_pow(hk_ctx* ctx, const void* fq12_in, const void* scalars_mont, size_t n, void* fq12_out);
 
 /* Element-wise linear combination of k <= 8 point vectors: out[i] = sum_j coeffs[j] * vecs[j][i], batch-normalised to
  * affine.  Replaces the aggregator's `prepared_input = s0 + s1*x0 + s2*x1 + s3*x2` (distributed-prover/src/

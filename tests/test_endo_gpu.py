@@ -189,11 +189,12 @@ def test_the_longest_vector_of_the_k_lane_form(ctx_bn254, monkeypatch):
     ctx = ctx_bn254
     cp, fc, cd = CURVES["bn254"], FrCodec("bn254"), Codec(CURVES["bn254"])
     rnd = random.Random(41)
-    for group, n_edge in ((2, 16384), (1, 32768)):
+    # G2 has a third form below them: 16 n <= 65 536 lanes (n <= 4 096) runs with every Fq2 value on a quad of lanes
+    for group, sizes in ((2, (4096, 4097, 16384, 16385)), (1, (32768, 32769))):
         gen = cp.g1_gen if group == 1 else cp.g2_gen
         vec = (cd.g1_vec if group == 1 else cd.g2_vec)([gen])
         fold = ctx.points_fold_g1 if group == 1 else ctx.points_fold_g2
-        for n in (n_edge, n_edge + 1):
+        for n in sizes:
             hi = ctx.fixed_base(group, vec, fc.enc([rnd.randrange(1, cp.r) for _ in range(n)])).copy()
             lo = ctx.fixed_base(group, vec, fc.enc([rnd.randrange(1, cp.r) for _ in range(n)])).copy()
             scal = fc.enc([rnd.randrange(cp.r) for _ in range(n)])

@@ -86,11 +86,10 @@ def test_multi_pairing_1024_bilinearity_and_cross_terms(ctx_bn254):
 
 
 @pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
-def test_gt_pow_matches_the_oracle(cname, ctx_bn254, ctx_bls, monkeypatch):
+def test_gt_pow_matches_the_oracle(cname, ctx_bn254, ctx_bls):
     """hk_gt_pow (one wavefront per element on the wave multiplier) against the tower oracle: the default form splits the
     exponent along the Frobenius (GT elements only: pi(z) = z^q, four parts <= 67 bits, one joint chain) - exponents 0, 1,
-    r - 1, the eigenvalue and its negative, 2^64, random; the plain 254-step chain (HK_GT_POW_PLAIN) also on a generic
-    Fq12 base."""
+    r - 1, the eigenvalue and its negative, 2^64, random; hk_fq12_pow (the plain 254-step chain) also on a generic Fq12 base."""
     ctx = _ctx(cname, ctx_bn254, ctx_bls)
     cp = CURVES[cname]
     T = pairing.tower(cname)
@@ -108,10 +107,9 @@ def test_gt_pow_matches_the_oracle(cname, ctx_bn254, ctx_bls, monkeypatch):
     out = ctx.gt_pow(enc(bases), fc.enc(exps))
     for k, (b, e) in enumerate(zip(bases, exps)):
         assert E.f12_dec(out[k].tobytes()) == T.f12_flat(T.f12_pow(b, e)), k
-    monkeypatch.setenv("HK_GT_POW_PLAIN", "1")
     bases2 = [g, T.f12_from_flat([rnd.randrange(cp.q) for _ in range(12)]), h]
     exps2 = [cp.r - 1, rnd.randrange(cp.r), rnd.randrange(cp.r)]
-    out2 = ctx.gt_pow(enc(bases2), fc.enc(exps2))
+    out2 = ctx.gt_pow(enc(bases2), fc.enc(exps2), in_gt=False)          # hk_fq12_pow
     for k, (b, e) in enumerate(zip(bases2, exps2)):
         assert E.f12_dec(out2[k].tobytes()) == T.f12_flat(T.f12_pow(b, e)), ("plain", k)
     assert np.array_equal(out2[0], out[2])
