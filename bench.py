@@ -348,7 +348,8 @@ class Job:
 
         def one(job):
             job[0](job[1])
-        list(self.pool.map(one, [(f, c) for c in self.classes.values() for f in (program, membership)]))
+        # the long tasks first: with as many workers as lanes, the short membership calls fill in behind the programs
+        list(self.pool.map(one, [(f, c) for f in (program, membership) for c in self.classes.values()]))
         return time.time() - t0
 
     def _gather(self, records):
