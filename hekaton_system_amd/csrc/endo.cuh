@@ -327,6 +327,7 @@ struct Fp2Q {
     __device__ __forceinline__ static Fp2Q dbl(const Fp2Q& a) { return add(a, a); }
     __device__ __forceinline__ static Fp2Q neg(const Fp2Q& a) { Fp2Q r; r.c0 = B::neg(a.c0); r.c1 = B::neg(a.c1); return r; }
     __device__ __forceinline__ static Fp2Q conj(const Fp2Q& a) { Fp2Q r; r.c0 = a.c0; r.c1 = B::neg(a.c1); return r; }
+    __device__ __forceinline__ static Fp2Q halve(const Fp2Q& a) { Fp2Q r; r.c0 = B::halve(a.c0); r.c1 = B::halve(a.c1); return r; }
     template <int CTRL>
     __device__ __forceinline__ static B quad_bcast(const B& v) {
         B r;
@@ -362,6 +363,10 @@ struct Fp2Q {
         return r;
     }
 };
+// the names the generic line steps of pairing.cuh call
+template <class P> __device__ __forceinline__ Fp2Q<P> f2m(const Fp2Q<P>& a, const Fp2Q<P>& b) { return Fp2Q<P>::mul(a, b); }
+template <class P> __device__ __forceinline__ Fp2Q<P> f2s(const Fp2Q<P>& a) { return Fp2Q<P>::sqr(a); }
+template <class P> __device__ __forceinline__ Fp2Q<P> f2_conj(const Fp2Q<P>& a) { return Fp2Q<P>::conj(a); }
 template <class P>
 __device__ __forceinline__ void st_vec(Fp2Q<P>* p, const Fp2Q<P>& v) {
     st_vec(&p->c0, v.c0);

@@ -18,12 +18,22 @@
 namespace hk {
 
 // ---- G2 line steps, homogeneous projective (X, Y, Z) (ark-ec bn/g2.rs, bls12/g2.rs) -------------------------
-template <class P> struct G2Proj { Fp2<P> x, y, z; };
-template <class P> struct LineCoeffs { Fp2<P> c0, c1, c2; };
+// Generic over the Fq2 representation F (Fp2<P>: one lane per value; Fp2Q<P>, endo.cuh: a quad of lanes per value - the
+// products go through the f2m / f2s overloads of F).
+template <class F> struct G2ProjF { F x, y, z; };
+template <class F> struct LineCoeffsF { F c0, c1, c2; };
+template <class P> using G2Proj = G2ProjF<Fp2<P>>;
+template <class P> using LineCoeffs = LineCoeffsF<Fp2<P>>;
+template <class F>
+HK_HD F f2_const(const u32 (&l)[2][F::Params::N]) {
+    F r;
+    HK_UNROLL for (int i = 0; i < F::Params::N; i++) { r.c0.v[i] = l[0][i]; r.c1.v[i] = l[1][i]; }
+    return r;
+}
 
-template <class P>
-HK_RARE LineCoeffs<P> pair_doubling_step(G2Proj<P>& r) {
-    typedef Fp2<P> F;
+template <class F>
+HK_RARE LineCoeffsF<F> pair_doubling_step(G2ProjF<F>& r) {
+    typedef typename F::Params P;
     typedef TowerParams<P> T;
     // the two divisions by 2 are halvings (add p if odd, shift), not products by 1/2: 4 of the step's 28 base-field products
     F a = F::halve(f2m(r.x, r.y));
@@ -36,7 +46,7 @@ HK_RARE LineCoeffs<P> pair_doubling_step(G2Proj<P>& r) {
         t.c1 = Fp<P>::add(c3.c0, c3.c1);
         e = F::dbl(F::dbl(t));
     } else {
-        e = f2m(fp2_const<P>(T::B_TWIST), c3);
+        e = f2m(f2_const<F>(T::B_TWIST), c3);
     }
     F f = F::add(F::add(e, e), e);
     F g = F::halve(F::add(b, f));
@@ -48,15 +58,15 @@ HK_RARE LineCoeffs<P> pair_doubling_step(G2Proj<P>& r) {
     r.y = F::sub(f2s(g), F::add(F::add(e_sq, e_sq), e_sq));
     r.z = f2m(b, h);
     F j3 = F::add(F::add(j, j), j);
-    LineCoeffs<P> l;
+    LineCoeffsF<F> l;
     if constexpr (T::TWIST_IS_D) { l.c0 = F::neg(h); l.c1 = j3; l.c2 = i; }
     else { l.c0 = i; l.c1 = j3; l.c2 = F::neg(h); }
     return l;
 }
 
-template <class P>
-HK_RARE LineCoeffs<P> pair_addition_step(G2Proj<P>& r, const Affine<Fp2<P>>& q) {
-    typedef Fp2<P> F;
+template <class F>
+HK_RARE LineCoeffsF<F> pair_addition_step(G2ProjF<F>& r, const Affine<F>& q) {
+    typedef typename F::Params P;
     typedef TowerParams<P> T;
     F theta = F::sub(r.y, f2m(q.y, r.z));
     F lambda = F::sub(r.x, f2m(q.x, r.z));
@@ -70,7 +80,7 @@ HK_RARE LineCoeffs<P> pair_addition_step(G2Proj<P>& r, const Affine<Fp2<P>>& q) 
     r.y = ny;
     r.z = f2m(r.z, e);
     F j = F::sub(f2m(theta, q.x), f2m(lambda, q.y));
-    LineCoeffs<P> l;
+    LineCoeffsF<F> l;
     if constexpr (T::TWIST_IS_D) { l.c0 = lambda; l.c1 = F::neg(theta); l.c2 = j; }
     else { l.c0 = j; l.c1 = F::neg(theta); l.c2 = lambda; }
     return l;
@@ -93,12 +103,12 @@ HK_RARE Fp12<P> pair_ell(const Fp12<P>& f, const LineCoeffs<P>& l, const Affine<
     return f12_mul(f, s);
 }
 
-template <class P>
-HK_HD Affine<Fp2<P>> pair_mul_by_char(const Affine<Fp2<P>>& q) {       // ark bn/g2.rs mul_by_char
-    typedef TowerParams<P> T;
-    Affine<Fp2<P>> r;
-    r.x = f2m(f2_conj(q.x), fp2_const<P>(T::MUL_BY_Q_X));
-    r.y = f2m(f2_conj(q.y), fp2_const<P>(T::MUL_BY_Q_Y));
+template <class F>
+HK_HD Affine<F> pair_mul_by_char(const Affine<F>& q) {       // ark bn/g2.rs mul_by_char
+    typedef TowerParams<typename F::Params> T;
+    Affine<F> r;
+    r.x = f2m(f2_conj(q.x), f2_const<F>(T::MUL_BY_Q_X));
+    r.y = f2m(f2_conj(q.y), f2_const<F>(T::MUL_BY_Q_Y));
     return r;
 }
 

@@ -33,7 +33,7 @@ hk_status PairRun<P>::gt_pow(hipStream_t s, const Fp12<P>* in, const void* scala
 
 template <class P>
 size_t PairRun<P>::max_private_bytes() {
-    const void* ks[] = {(const void*)k_pair_lines<P>, (const void*)k_pair_tree_lines<P>, (const void*)k_pair_tree<P>,
+    const void* ks[] = {(const void*)k_pair_lines<Fp2<P>>, (const void*)k_pair_lines<Fp2Q<P>>, (const void*)k_pair_tree_lines<P>, (const void*)k_pair_tree<P>,
                         (const void*)k_pair_horner<P>,
                         (const void*)k_gt_pow<P, typename ScalarOfQ<P>::type>, (const void*)k_gt_pow_endo<P, typename ScalarOfQ<P>::type>};
     const void* serial[] = {(const void*)k_pair_miller<P>, (const void*)k_f12_product<P>, (const void*)k_final_exp<P>};
@@ -96,7 +96,13 @@ hk_status PairRun<P>::run(hipStream_t s, const Affine<Fp<P>>* g1, const Affine<F
         Fp12<P>* pp[2];
         pp[0] = reinterpret_cast<Fp12<P>*>(reinterpret_cast<char*>(miller) + lines_bytes);
         pp[1] = pp[0] + (size_t)count * S * g0;
-        hipLaunchKernelGGL((k_pair_lines<P>), dim3((n + 63) / 64, n_r), dim3(64), 0, s, g2, n, n_r, loop, S, lines);
+        // few points: a quad of lanes per point (4 n n_r lanes still at most one wave per SIMD)
+        const bool quad = (size_t)n * n_r * 4 <= SPLIT_MAX_LANES && getenv("HK_ENDO_NO_QUAD") == nullptr;
+        if (quad)
+            hipLaunchKernelGGL((k_pair_lines<Fp2Q<P>>), dim3((4 * n + 63) / 64, n_r), dim3(64), 0, s,
+                               (const Affine<Fp2Q<P>>*)g2, n, n_r, loop, S, lines);
+        else
+            hipLaunchKernelGGL((k_pair_lines<Fp2<P>>), dim3((n + 63) / 64, n_r), dim3(64), 0, s, g2, n, n_r, loop, S, lines);
         HK_DBG(s, "k_pair_lines");
         hipLaunchKernelGGL((k_pair_tree_lines<P>), dim3(g0, count * S), dim3(64), lds_tree, s, (const Line6<P>*)lines, g1, n, 16u, n_r, S, pl, pp[0]);
         HK_DBG(s, "k_pair_tree_lines");

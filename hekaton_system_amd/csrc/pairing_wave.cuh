@@ -306,16 +306,19 @@ template <class P> struct Line6 { Fp2<P> c0, c1, c2; };
 // writes all-zero coefficients (no real step does: its c0 / c2 carries 2yz resp. lambda, non-zero on the prime-order
 // subgroup), which the tree kernel reads as "this pair contributes 1".  The evaluation at the lhs points (4 Fq products per
 // line and lhs vector) is NOT part of this serial chain: with four lhs vectors it was 40 % of it.
-template <class P>
+// F: the Fq2 representation - Fp2<P> (one lane per G2 point) or, for short vectors, Fp2Q<P> (a quad of lanes per point:
+// every Fq2 product of the chain is ONE base-field product per lane, endo.cuh).  grid: (ceil(n L / 64), n_r), L lanes per point.
+template <class F>
 __global__ void __launch_bounds__(64)
-k_pair_lines(const Affine<Fp2<P>>* __restrict__ g2, u32 n, u32 n_r, PairLoop loop, u32 S, Line6<P>* __restrict__ lines) {
+k_pair_lines(const Affine<F>* __restrict__ g2, u32 n, u32 n_r, PairLoop loop, u32 S, Line6<typename F::Params>* __restrict__ lines) {
+    typedef typename F::Params P;
     typedef TowerParams<P> T;
-    typedef Fp2<P> F;
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;           // grid: (ceil(n / 64), n_r)
+    constexpr int L = LanesPerValue<F>::value;
+    u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / L, b = blockIdx.y;
     if (i >= n) return;
     Affine<F> q = ld_vec(&g2[(size_t)b * n + i]);
     bool q_inf = q.is_inf();
-    G2Proj<P> r;
+    G2ProjF<F> r;
     r.x = q.x; r.y = q.y; r.z = F::one();
     Affine<F> nq = q;
     nq.y = F::neg(q.y);
@@ -326,12 +329,12 @@ k_pair_lines(const Affine<Fp2<P>>* __restrict__ g2, u32 n, u32 n_r, PairLoop loo
         q2.y = F::neg(q2.y);
     }
     u32 s = 0;
-    auto emit = [&](const LineCoeffs<P>& l) {
-        Line6<P>* dst = &lines[((size_t)b * S + s) * n + i];
-        st_vec(&dst->c0, l.c0); st_vec(&dst->c1, l.c1); st_vec(&dst->c2, l.c2);
+    auto emit = [&](const LineCoeffsF<F>& l) {
+        F* dst = reinterpret_cast<F*>(&lines[((size_t)b * S + s) * n + i]);          // Line6: three Fq2, same layout
+        st_vec(&dst[0], l.c0); st_vec(&dst[1], l.c1); st_vec(&dst[2], l.c2);
         s++;
     };
-    LineCoeffs<P> dummy; dummy.c0 = F::zero(); dummy.c1 = F::zero(); dummy.c2 = F::zero();
+    LineCoeffsF<F> dummy; dummy.c0 = F::zero(); dummy.c1 = F::zero(); dummy.c2 = F::zero();
     HK_NOUNROLL for (int k = loop.len - 1; k >= 1; k--) {
         emit(q_inf ? dummy : pair_doubling_step(r));
         int d = loop.digits[k - 1];
