@@ -1,3 +1,4 @@
+#include <utility>
 // hk_core.hip — context / lane management and the C ABI entry points (dispatch to per-curve code).
 #include "hk_internal.h"
 #include <hsa/hsa.h>
@@ -135,6 +136,18 @@ LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
                 if (l->stream) (void)hipStreamDestroy(l->stream);
                 delete l;
                 break;
+            }
+            // The runtime hands hardware queues to streams round robin in creation order; with 20 queues and five streams
+            // per lane the FIRST stream of lane k and of lane k + 4 share a queue, and two concurrent single-kernel calls
+            // (the aggregator's sweeps and pairings, the witness programs) on those lanes run one after the other.  Lanes
+            // 4 .. 7 therefore work on their second stream, lanes 8 .. 11 on their third, ...: queues 0, 5, 10, 15, then
+            // 1, 6, 11, 16, then 2, 7, ...  (the five streams of a lane are interchangeable for hk_prove's fork / join).
+            // Streams stay lazily created, lane by lane: creating all of them at once made a second context of the
+            // process abort with HSA_STATUS_ERROR_OUT_OF_RESOURCES in its first scratch pre-sizing (twenty new queues
+            // wanting their rings while the previous context's were still held).
+            {
+                size_t rot = (ctx->lanes.size() / 4) % 5;
+                if (rot) std::swap(l->stream, l->aux[rot - 1]);
             }
             if (ctx->presize_kernel && !getenv("HK_NO_SCRATCH_PRESIZE")) {
                 // one wave of the deepest frame on each of the lane's streams, in creation order (see k_scratch_presize)
