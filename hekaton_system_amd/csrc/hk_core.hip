@@ -146,8 +146,16 @@ LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
             // process abort with HSA_STATUS_ERROR_OUT_OF_RESOURCES in its first scratch pre-sizing (twenty new queues
             // wanting their rings while the previous context's were still held).
             {
-                size_t rot = (ctx->lanes.size() / 4) % 5;
-                if (rot) std::swap(l->stream, l->aux[rot - 1]);
+                // all five roles rotate (HK_LANE_ROT positions per group of four lanes, default 1): not only the working
+                // stream of single-kernel calls moves to another queue, hk_prove's heavy side streams of lanes k and
+                // k + 4 stop sharing queues role by role
+                static const size_t step = [] { const char* e = getenv("HK_LANE_ROT"); return e ? (size_t)atoi(e) % 5 : (size_t)1; }();
+                size_t rot = ((ctx->lanes.size() / 4) * step) % 5;
+                if (rot) {
+                    hipStream_t all[5] = {l->stream, l->aux[0], l->aux[1], l->aux[2], l->aux[3]};
+                    l->stream = all[rot % 5];
+                    for (size_t j = 0; j < 4; j++) l->aux[j] = all[(rot + 1 + j) % 5];
+                }
             }
             if (ctx->presize_kernel && !getenv("HK_NO_SCRATCH_PRESIZE")) {
                 // one wave of the deepest frame on each of the lane's streams, in creation order (see k_scratch_presize)
