@@ -3,6 +3,7 @@
 // (hk_<curve>_{g1,g2,fr}.hip) and referenced here through extern templates.
 #pragma once
 #include "msm_driver.cuh"
+#include "endo.cuh"
 
 namespace hk {
 
@@ -65,6 +66,25 @@ struct Ops {
         LaneGuard g(ctx);
         Lane* L = g.lane;
         if (!L) return HK_ERR_DEVICE;
+        if (n * EndoOf<F>::K <= SPLIT_MAX_LANES && !getenv("HK_MSM_NO_SMALL")) {
+            // short vector, no tables: a Pippenger pass would end in ~254 serial doublings (3 / 8.5 ms whatever n)
+            size_t need = al256(n * sizeof(Fr)) + al256(n * sizeof(Affine<F>)) + al256(n * sizeof(XYZZ<F>)) +
+                          al256(endo_tab_bytes<F>(n)) + al256(sizeof(XYZZ<F>)) + al256(sizeof(Affine<F>)) + 4096;
+            HK_TRY(L->reserve(need));
+            const void *sc_d, *b_d;
+            HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sc_d));
+            HK_TRY(to_device(L, bases, n * sizeof(Affine<F>), &b_d));
+            XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
+            XYZZ<F>* tab = (XYZZ<F>*)L->alloc_n<unsigned char>(endo_tab_bytes<F>(n));
+            XYZZ<F>* res = L->alloc_n<XYZZ<F>>(1);
+            Affine<F>* aff = L->alloc_n<Affine<F>>(1);
+            if (!xy || !tab || !res || !aff) return HK_ERR_NOMEM;
+            HK_TRY(MsmRun<F>::small_msm(L->stream, (const Affine<F>*)b_d, sc_d, mont, (u32)n, tab, xy, res));
+            HK_TRY(MsmRun<F>::to_affine(L->stream, res, aff, 1));
+            HK_HIP(hipMemcpyAsync(out, aff, sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
+            HK_HIP(hipStreamSynchronize(L->stream));
+            return HK_OK;
+        }
         u32 c = msm_pick_c_plain(n, C::FR_BITS);
         MsmPlan p = msm_make_plan((u32)n, C::FR_BITS, c, 0xffffffffu, ctx->max_lanes0, C::Fr::Params::MOD, C::Fr::Params::N);
         size_t need = al256(n * sizeof(Fr)) + al256(n * sizeof(Affine<F>)) + msm_sort_bytes(p) +

@@ -405,7 +405,7 @@ template <class F> struct SplitVecs { const Affine<F>* lo[FOLD_MAX]; const Affin
 template <class Fr, class F, bool UNIFORM>
 __global__ void __launch_bounds__(64)
 k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, u32 n, EndoSplit<EndoOf<F>::K> E,
-                   Jac<F>* __restrict__ tab, XYZZ<F>* __restrict__ out) {
+                   Jac<F>* __restrict__ tab, XYZZ<F>* __restrict__ out, int scalars_mont) {
     constexpr int K = EndoOf<F>::K;
     constexpr int ND = SplitDigits<F>::ND;                        // nibbles of m'
     constexpr int L = LanesPerValue<F>::value;                    // 4: every value on a quad of lanes (Fp2Q), t = the quad
@@ -428,7 +428,8 @@ k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, 
             HK_UNROLL for (int l = 0; l < 6; l++) m[l] = c.v[l];
             negate = (neg_all >> j) & 1u;
         } else {
-            Fr s = Fr::from_mont(ld_vec(&scalars[i]));
+            Fr s = ld_vec(&scalars[i]);
+            if (scalars_mont) s = Fr::from_mont(s);                  // else: canonical integers < r (hk_msm with mont = 0)
             u32 c[8];
             HK_UNROLL for (int l = 0; l < 8; l++) c[l] = s.v[l];
             u32 mag[K][6];
@@ -481,6 +482,25 @@ k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, 
         if (lo) o = ec_madd_ni(o, ld_vec(&lo[i]));
         st_vec(&out[i], o);
     }
+}
+// out[0] = sum of n XYZZ points: one workgroup, strided partial sums, LDS tree (the tail of a SMALL one-off MSM:
+// hk_msm_g1 / _g2 over caller-supplied bases with n K <= SPLIT_MAX_LANES run as n element-wise products + this sum -
+// without shift tables a Pippenger pass ends in ~254 serial doublings, 3 ms in G1 and 8.5 ms in G2 whatever n)
+template <class F> struct PointsSum { static constexpr int THREADS = sizeof(XYZZ<F>) > 256 ? 128 : 256; };   // LDS <= 64 KiB
+template <class F>
+__global__ void __launch_bounds__(PointsSum<F>::THREADS)
+k_points_sum(const XYZZ<F>* __restrict__ in, u32 n, XYZZ<F>* __restrict__ out) {
+    constexpr u32 T = PointsSum<F>::THREADS;
+    __shared__ XYZZ<F> sh[T];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    HK_NOUNROLL for (u32 i = threadIdx.x; i < n; i += T) acc = ec_add_ni(acc, ld_vec(&in[i]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    HK_NOUNROLL for (u32 off = T / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { XYZZ<F> t = ec_add_ni(sh[threadIdx.x], sh[threadIdx.x + off]); sh[threadIdx.x] = t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_vec(out, sh[0]);
 }
 #endif
 

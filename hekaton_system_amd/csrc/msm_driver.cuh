@@ -66,6 +66,9 @@ struct MsmRun {
     // k_points_fold_endo / k_points_mul_split); tab: endo_tab_bytes(n) of scratch
     static hk_status fold_endo(hipStream_t s, u32 k, const Affine<F>* const* lo, const Affine<F>* const* hi, const void* coeffs_mont,
                                u32 neg_mask, u32 n, XYZZ<F>* tab, XYZZ<F>* xy, F* pref, Affine<F>* out);
+    // a short one-off MSM without tables (n K <= SPLIT_MAX_LANES): element-wise products + one workgroup's sum; result: 1 XYZZ
+    static hk_status small_msm(hipStream_t s, const Affine<F>* bases, const void* scalars, int mont, u32 n, XYZZ<F>* tab,
+                               XYZZ<F>* xy, XYZZ<F>* result);
     // largest private-memory ("scratch") frame per lane among this flavour's kernels, from the loaded code object
     // (hipFuncGetAttributes): what sizes a hardware queue's scratch ring
     static size_t max_private_bytes();

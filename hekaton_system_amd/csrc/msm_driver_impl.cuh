@@ -131,7 +131,7 @@ size_t MsmRun<F>::max_private_bytes() {
                         (const void*)k_msm_reduce_fused<F>, (const void*)k_msm_bucket_reduce<F>,
                         (const void*)k_msm_window_sum<F>, (const void*)k_msm_final<F>, (const void*)k_to_affine<F>,
                         (const void*)k_msm_build_tables<F>, (const void*)k_batch_affine<F>, (const void*)k_fb_table<F>,
-                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>, (const void*)k_points_fold_endo<Fr, F>, (const void*)k_points_mul_split<Fr, F, true>, (const void*)k_points_mul_split<Fr, F, false>,
+                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>, (const void*)k_points_fold_endo<Fr, F>, (const void*)k_points_mul_split<Fr, F, true>, (const void*)k_points_mul_split<Fr, F, false>, (const void*)k_points_sum<F>,
                         (const void*)k_points_lincomb<Fr, F>};
     size_t m = 0;
     for (const void* k : ks) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }
@@ -169,7 +169,7 @@ hk_status MsmRun<F>::batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* o
 // the K-lane sweep (endo.cuh): for G2 with few elements every Fq2 value on a quad of lanes (Fp2Q), else one lane per value
 template <class Fr, class P, bool UNIFORM>
 static inline void launch_mul_split(hipStream_t s, const SplitVecs<Fp2<P>>& v, u32 k, const Fr* scalars, u32 neg_mask, u32 n,
-                                    const EndoSplit<4>& E, Jac<Fp2<P>>* tab, XYZZ<Fp2<P>>* xy) {
+                                    const EndoSplit<4>& E, Jac<Fp2<P>>* tab, XYZZ<Fp2<P>>* xy, int scalars_mont = 1) {
     const bool no_quad = getenv("HK_ENDO_NO_QUAD") != nullptr;
     u32 lanes = n * 4;
     if (!no_quad && (size_t)lanes * 4 <= SPLIT_MAX_LANES) {
@@ -177,17 +177,17 @@ static inline void launch_mul_split(hipStream_t s, const SplitVecs<Fp2<P>>& v, u
         SplitVecs<Q> vq;
         for (int y = 0; y < FOLD_MAX; y++) { vq.lo[y] = (const Affine<Q>*)v.lo[y]; vq.pts[y] = (const Affine<Q>*)v.pts[y]; }
         hipLaunchKernelGGL((k_points_mul_split<Fr, Q, UNIFORM>), dim3((lanes * 4 + 63) / 64, k), dim3(64), 0, s, vq, scalars,
-                           neg_mask, n, E, (Jac<Q>*)tab, (XYZZ<Q>*)xy);
+                           neg_mask, n, E, (Jac<Q>*)tab, (XYZZ<Q>*)xy, scalars_mont);
     } else {
         hipLaunchKernelGGL((k_points_mul_split<Fr, Fp2<P>, UNIFORM>), dim3((lanes + 63) / 64, k), dim3(64), 0, s, v, scalars,
-                           neg_mask, n, E, tab, xy);
+                           neg_mask, n, E, tab, xy, scalars_mont);
     }
 }
 template <class Fr, class P, bool UNIFORM>
 static inline void launch_mul_split(hipStream_t s, const SplitVecs<Fp<P>>& v, u32 k, const Fr* scalars, u32 neg_mask, u32 n,
-                                    const EndoSplit<2>& E, Jac<Fp<P>>* tab, XYZZ<Fp<P>>* xy) {
+                                    const EndoSplit<2>& E, Jac<Fp<P>>* tab, XYZZ<Fp<P>>* xy, int scalars_mont = 1) {
     hipLaunchKernelGGL((k_points_mul_split<Fr, Fp<P>, UNIFORM>), dim3((n * 2 + 63) / 64, k), dim3(64), 0, s, v, scalars,
-                       neg_mask, n, E, tab, xy);
+                       neg_mask, n, E, tab, xy, scalars_mont);
 }
 
 template <class F>
@@ -214,6 +214,22 @@ hk_status MsmRun<F>::scalar_mul_each(hipStream_t s, const Affine<F>* pts, const 
     }
     HK_HIP(hipGetLastError());
     return batch_affine(s, xy, out, pref, n);
+}
+
+// sum_i s_i P_i for a SHORT vector without tables: n element-wise products over the endomorphism (k_points_mul_split),
+// then one workgroup's sum (k_points_sum).  scalars: Montgomery (mont != 0) or canonical integers.
+template <class F>
+hk_status MsmRun<F>::small_msm(hipStream_t s, const Affine<F>* bases, const void* scalars, int mont, u32 n, XYZZ<F>* tab,
+                               XYZZ<F>* xy, XYZZ<F>* result) {
+    typedef typename ScalarOf<F>::type Fr;
+    if (n == 0 || (size_t)n * EndoOf<F>::K > SPLIT_MAX_LANES) return HK_ERR_ARG;
+    static const auto E = EndoOf<F>::split();
+    SplitVecs<F> v = {};
+    v.pts[0] = bases;
+    launch_mul_split<Fr, typename F::Params, false>(s, v, 1u, (const Fr*)scalars, 0u, n, E, reinterpret_cast<Jac<F>*>(tab), xy, mont ? 1 : 0);
+    hipLaunchKernelGGL((k_points_sum<F>), dim3(1), dim3(PointsSum<F>::THREADS), 0, s, (const XYZZ<F>*)xy, n, result);
+    HK_HIP(hipGetLastError());
+    return HK_OK;
 }
 
 template <class F>

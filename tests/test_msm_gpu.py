@@ -28,6 +28,15 @@ def test_msm_small_vs_oracle(group, n, ctx_bn254):
     _msm_case("bn254", group, n, ctx_bn254, None)
 
 
+@pytest.mark.parametrize("n", [33, 300])
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_msm_small_by_the_bucket_method(group, n, ctx_bn254, monkeypatch):
+    """Short one-off MSMs run as element-wise products + a sum (MsmRun::small_msm) by default; HK_MSM_NO_SMALL sends them
+    through the Pippenger pass the long ones take - the same cases, the same oracle."""
+    monkeypatch.setenv("HK_MSM_NO_SMALL", "1")
+    _msm_case("bn254", group, n, ctx_bn254, None)
+
+
 def _msm_case(cname, group, n, ctx_bn254, ctx_bls):
     cp = CURVES[cname]
     ctx = _ctx(cname, ctx_bn254, ctx_bls)
