@@ -679,8 +679,9 @@ struct BasesImpl {
     int group = 1;
     u32 n = 0;
     MsmPlan plan;
-    void* tab = nullptr;        // [F][n] Affine<Fq> or Affine<Fq2>
+    void* tab = nullptr;        // [F][n] Affine<Fq> or Affine<Fq2>; [1][n] when the set never needs its shift tables
     size_t bytes = 0;
+    bool has_tables = true;     // false: a short G2 set - every MSM over it runs as MsmRun::small_msm
 };
 
 template <class C>
@@ -696,10 +697,14 @@ hk_status Ops<C>::bases_upload(hk_ctx* ctx, int group, const void* bases, size_t
     b->plan = msm_make_plan((u32)n, C::FR_BITS, msm_pick_c_tables(n, C::FR_BITS), 1u, ctx->max_lanes0, C::Fr::Params::MOD, C::Fr::Params::N);
     auto build = [&](auto ftag) -> hk_status {
         typedef decltype(ftag) F;
-        size_t bytes = (size_t)b->plan.F * n * sizeof(Affine<F>);
+        // a short G2 set is never multiplied through its tables (msm_bases): the 15 x (16 doublings + one inversion) per
+        // base of their construction - 10 ms per set, most of `tipa.setup` - are skipped
+        b->has_tables = !(sizeof(F) > sizeof(Fq) && n <= 2048 && !getenv("HK_MSM_NO_SMALL"));
+        size_t bytes = (size_t)(b->has_tables ? b->plan.F : 1u) * n * sizeof(Affine<F>);
         if (hipMalloc(&b->tab, bytes) != hipSuccess) { (void)hipGetLastError(); return HK_ERR_NOMEM; }
         b->bytes = bytes;
         HK_HIP(hipMemcpy(b->tab, bases, n * sizeof(Affine<F>), h2d_kind(bases)));
+        if (!b->has_tables) return HK_OK;
         return MsmRun<F>::build_tables(0, (Affine<F>*)b->tab, (u32)n, b->plan.F, b->plan.c * b->plan.WP);
     };
     hk_status st = group == 1 ? build(Fq()) : build(Fq2());
@@ -733,7 +738,7 @@ hk_status Ops<C>::msm_bases(hk_ctx* ctx, const hk_bases* h, const void* scalars,
         LaneGuard g(ctx);
         Lane* L = g.lane;
         if (!L) return HK_ERR_DEVICE;
-        if (sizeof(F) > sizeof(Fq) && n <= 2048 && !getenv("HK_MSM_NO_SMALL")) {
+        if (!b->has_tables || (sizeof(F) > sizeof(Fq) && n <= 2048 && !getenv("HK_MSM_NO_SMALL"))) {
             // a short G2 MSM: even with the tables' bucket pass free of a Horner tail, n element-wise products over psi +
             // one sum are quicker (1.9 - 2.4 ms against 2.3 - 3.0; G1 stays with the tables: 1.0 - 1.2 ms against 1.4 - 1.5)
             HK_TRY(L->reserve(al256(n * sizeof(Fr)) + al256(n * sizeof(XYZZ<F>)) + al256(endo_tab_bytes<F>(n)) +

@@ -58,15 +58,16 @@ def setup(ctx, curve, n, alpha, beta):
         pa[i] = pa[i - 1] * alpha % r
         pb[i] = pb[i - 1] * beta % r
     G1, G2 = fc.g1(p["g1"]), fc.g2(p["g2"])
-    g_a = np.asarray(ctx.fixed_base(1, G1, fc.enc(pa)))
-    g_b = np.asarray(ctx.fixed_base(1, G1, fc.enc(pb)))
-    h_a = np.asarray(ctx.fixed_base(2, G2, fc.enc(pa[:n])))
-    h_b = np.asarray(ctx.fixed_base(2, G2, fc.enc(pb[:n])))
-    g1b = ctx.g1_bytes
-    ck = IPCommKey(v1=h_a, v2=h_b, w1=g_a[n * g1b:].copy(), w2=g_b[n * g1b:].copy(), n=n)
-    srs = Srs(n, g_a, g_b, h_a, h_b, ck)
-    srs.resident = dict(g_alpha=ctx.bases_upload(1, g_a), g_beta=ctx.bases_upload(1, g_b),
-                        h_alpha=ctx.bases_upload(2, h_a), h_beta=ctx.bases_upload(2, h_b))
+    # four independent fixed-base sweeps, then four independent table builds: issued together (one lane each)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        fs = [pool.submit(ctx.fixed_base, g, base, fc.enc(sc)) for g, base, sc in
+              ((1, G1, pa), (1, G1, pb), (2, G2, pa[:n]), (2, G2, pb[:n]))]
+        g_a, g_b, h_a, h_b = (np.asarray(f.result()) for f in fs)
+        g1b = ctx.g1_bytes
+        ck = IPCommKey(v1=h_a, v2=h_b, w1=g_a[n * g1b:].copy(), w2=g_b[n * g1b:].copy(), n=n)
+        srs = Srs(n, g_a, g_b, h_a, h_b, ck)
+        ups = [pool.submit(ctx.bases_upload, g, v) for g, v in ((1, g_a), (1, g_b), (2, h_a), (2, h_b))]
+        srs.resident = dict(zip(("g_alpha", "g_beta", "h_alpha", "h_beta"), (f.result() for f in ups)))
     return srs
 
 
