@@ -285,6 +285,7 @@ class Job:
                                 r_b=self.fc.enc1(rr), s_b=self.fc.enc1(ss))
         self.ctx.set_profiling(True)
         self.pool = ThreadPoolExecutor(max_workers=args.threads)
+        self.wg_pool = ThreadPoolExecutor(max_workers=5)        # the classes' witness programs, beside the stage-0 round
         self.accum_ms, self.accum_n, self.accum_h, self.phase = [], [], [], {}
         self.gather_s = 0.0
         self.wait_s = 0.0
@@ -316,40 +317,41 @@ class Job:
         t = self.ctx.last_timings()
         return Stage1Response(i, Proof(a, b, cc, [com])).to_record(), t
 
-    def _generate_witnesses(self):
-        """Stage-1 witness generation for every subcircuit of the shard, one batched hk_wprog_run + hk_poseidon_path per
-        proving-key class (classes run concurrently): the host computes each subcircuit's ~50 full-width values (portal
-        entries, running evaluations, address-step flags), the device everything else (the SHA-256 chains' bits, the
-        Poseidon membership block)."""
+    def _start_witness_programs(self):
+        """The challenge-independent part of stage-1 witness generation - each class's word program and the expansion of
+        its bits into the assignments (16 ms, one dependent chain per subcircuit) - issued when the step begins, beside the
+        stage-0 round: a subcircuit's SHA-256 trace does not depend on the round's challenges, its running evaluations
+        and its execution-tree leaf do (_finish_witnesses)."""
+        self._wg_t0 = time.time()
+        self._wg_futs = [self.wg_pool.submit(lambda c=c: c["wprog"].run(c["wg_inputs"], [], [], out=c["zbig"]))
+                         for c in self.classes.values()]
+
+    def _finish_witnesses(self):
+        """After the first round: wait for the programs, then per class the ~50 full-width values the host computes
+        (portal entries, running evaluations, address-step flags: hk_assignment_scatter) and the membership block
+        (execution-tree leaf hash + path, subcircuit_circuit.rs:233-252: hk_poseidon_path), classes side by side.
+        Returns the seconds this added to the step (the programs' own time is hidden behind round 1 unless they are
+        still running here)."""
         from hekaton_system_amd.sha_circuit import full_values, poseidon_inputs
         t0 = time.time()
-
         trace = bool(os.environ.get("HK_WG_TRACE"))
+        for f in self._wg_futs:
+            f.result()
+        t1 = time.time()
 
-        def program(c):
-            circ = c["circ"]
-            ta = time.time()
-            cols, vals = full_values(circ, c["wg_ws"])
-            tb = time.time()
-            c["wprog"].run(c["wg_inputs"], cols, vals, out=c["zbig"])
-            if trace:
-                log("witness gen, class of %d: host full values %.1f ms, word program + expansion %.1f"
-                    % (len(c["wg_ws"]), (tb - ta) * 1e3, (time.time() - tb) * 1e3))
+        def full(c):
+            cols, vals = full_values(c["circ"], c["wg_ws"])
+            c["wprog"].scatter(cols, vals, c["zbig"])
 
         def membership(c):
-            # the membership block (execution-tree leaf hash + path, subcircuit_circuit.rs:233-252) from the request's
-            # leaf and path, computed on the device into its own columns of the same assignments - beside the program
             circ = c["circ"]
-            ta = time.time()
             leaves, sibs, idx = poseidon_inputs(circ, c["wg_ws"])
             self.ctx.poseidon_path(self.poseidon_params, leaves, sibs, idx, circ.n_v, circ.pos_col0, c["zbig"])
-            if trace:
-                log("witness gen, class of %d: poseidon path %.1f ms" % (len(c["wg_ws"]), (time.time() - ta) * 1e3))
 
-        def one(job):
-            job[0](job[1])
-        # the long tasks first: with as many workers as lanes, the short membership calls fill in behind the programs
-        list(self.pool.map(one, [(f, c) for f in (program, membership) for c in self.classes.values()]))
+        list(self.pool.map(lambda job: job[0](job[1]), [(f, c) for f in (membership, full) for c in self.classes.values()]))
+        if trace:
+            log("witness gen: programs started %.1f ms before the gather ended, waited %.1f ms for them, full values + membership %.1f ms"
+                % ((t0 - self._wg_t0) * 1e3, (t1 - t0) * 1e3, (time.time() - t1) * 1e3))
         return time.time() - t0
 
     def _gather(self, records):
@@ -377,12 +379,14 @@ class Job:
 
     def step(self, record):
         g1b = self.ctx.g1_bytes
+        if self.args.witness_gen:
+            self._start_witness_programs()
         r0 = list(self.pool.map(self._stage0, self.shard))
         all0 = self._gather([r for r, _ in r0])                           # node.rs:500-506
         assert len(all0) == self.n_total
         coms = [r[8:8 + g1b] for r, _ in r0]
         if self.args.witness_gen:
-            self.wg_s += self._generate_witnesses()
+            self.wg_s += self._finish_witnesses()
         r1 = list(self.pool.map(self._stage1, zip(self.shard, coms)))
         all1 = self._gather([r for r, _ in r1])                           # node.rs:526-533
         assert len(all1) == self.n_total

@@ -67,7 +67,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_points_fold_many_g1", "hk_points_fold_many_g2", "hk_pairing_pairs", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_fq12_pow", "hk_poseidon_path"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_points_fold_many_g1", "hk_points_fold_many_g2", "hk_pairing_pairs", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_fq12_pow", "hk_poseidon_path", "hk_assignment_scatter"]
 
 _lib = None
 
@@ -127,6 +127,7 @@ def load():
         lib.hk_wprog_free.argtypes = [vp]
         lib.hk_wprog_free.restype = None
         lib.hk_wprog_run.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
+        lib.hk_assignment_scatter.argtypes = [vp, vp, vp, sz, sz, sz, vp]
     if hasattr(lib, "hk_gt_pow"):
         lib.hk_gt_pow.argtypes = [vp, vp, vp, sz, vp]
         lib.hk_fq12_pow.argtypes = [vp, vp, vp, sz, vp]
@@ -545,6 +546,15 @@ class WordProgram:
                                         cols.ctypes.data if cols.size else None, vals.ctypes.data if cols.size else None,
                                         cols.size, buf.ptr), "hk_wprog_run")
         return buf
+
+    def scatter(self, full_cols, full_vals, out):
+        """The full-width values alone (hk_assignment_scatter), into assignments `run(inputs, [], [], out=...)` produced."""
+        cols = np.ascontiguousarray(full_cols, dtype=np.uint32)
+        vals = np.ascontiguousarray(full_vals, dtype=np.uint8)
+        batch = vals.size // max(1, cols.size * self.ctx.fr_bytes)
+        check(self.ctx.lib.hk_assignment_scatter(self.ctx.handle, cols.ctypes.data, vals.ctypes.data, cols.size, batch, self.n_v,
+                                                 out.ptr), "hk_assignment_scatter")
+        return out
 
     def free(self):
         if self.handle:

@@ -134,6 +134,7 @@ struct Ops {
     static hk_status points_lincomb(hk_ctx*, int, const void* const*, const void*, size_t, size_t, void*);
     template <class F>
     static hk_status points_fold(hk_ctx*, size_t, const void* const*, const void* const*, const void*, unsigned, size_t, void* const*);
+    static hk_status assignment_scatter(hk_ctx*, const uint32_t*, const void*, size_t, size_t, size_t, void*);
     static hk_status pairing_pairs(hk_ctx*, const void* const*, size_t, const void* const*, size_t, const uint32_t*, const uint32_t*, size_t,
                                    size_t, void*);
     static hk_status points_fold_many(hk_ctx*, int, size_t, const void* const*, const void* const*, const void*, unsigned, size_t, void* const*);
@@ -165,7 +166,7 @@ struct Ops {
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
                                    sizeof(Fp12<typename Fq::Params>), &points_lincomb, &points_fold_g2, &points_fold_g1, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow,
-                                   &max_private_bytes, &poseidon_path, &points_fold_many, &pairing_pairs};
+                                   &max_private_bytes, &poseidon_path, &points_fold_many, &pairing_pairs, &assignment_scatter};
         return &t;
     }
 };

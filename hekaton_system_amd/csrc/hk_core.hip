@@ -398,6 +398,11 @@ hk_status hk_wprog_run(hk_ctx* ctx, const hk_wprog* w, const uint32_t* inputs, s
     if (!ctx || !w || w->ctx != ctx || !z_out || (batch && !inputs) || (n_full && (!full_cols || !full_vals_mont))) return HK_ERR_ARG;
     return ctx->ops->wprog_run(ctx, w, inputs, batch, full_cols, full_vals_mont, n_full, z_out);
 }
+hk_status hk_assignment_scatter(hk_ctx* ctx, const uint32_t* full_cols, const void* full_vals_mont, size_t n_full, size_t batch,
+                                size_t n_v, void* z_out) {
+    if (!ctx || !z_out || (n_full && batch && (!full_cols || !full_vals_mont))) return HK_ERR_ARG;
+    return ctx->ops->assignment_scatter(ctx, full_cols, full_vals_mont, n_full, batch, n_v, z_out);
+}
 hk_status hk_assignment_from_bits(hk_ctx* ctx, const void* bits, size_t n_v, const uint32_t* full_cols,
                                   const void* full_vals_mont, size_t n_full, void* z_out) {
     if (!ctx || !z_out || (n_v && !bits) || (n_full && (!full_cols || !full_vals_mont))) return HK_ERR_ARG;

@@ -136,6 +136,8 @@ struct CurveOps {
                                   const void* coeffs, unsigned neg_mask, size_t n, void* const* out);
     hk_status (*pairing_pairs)(hk_ctx*, const void* const* lhs, size_t n_lhs, const void* const* rhs, size_t n_rhs,
                                const uint32_t* pair_lhs, const uint32_t* pair_rhs, size_t n_pairs, size_t n, void* out);
+    hk_status (*assignment_scatter)(hk_ctx*, const uint32_t* full_cols, const void* full_vals, size_t n_full, size_t batch,
+                                    size_t n_v, void* z_out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

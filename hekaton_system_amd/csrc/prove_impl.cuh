@@ -1080,6 +1080,29 @@ hk_status Ops<C>::wprog_run(hk_ctx* ctx, const hk_wprog* h, const uint32_t* inpu
     return HK_OK;
 }
 
+// z_out[b][full_cols[j]] = full_vals[b][j]: the full-width values alone, for a caller that ran the class's word program
+// earlier (hk_wprog_run with n_full = 0) and learns the values that depend on the round's challenges later
+template <class C>
+hk_status Ops<C>::assignment_scatter(hk_ctx* ctx, const uint32_t* full_cols, const void* full_vals, size_t n_full, size_t batch,
+                                     size_t n_v, void* z_out) {
+    if (batch == 0 || n_full == 0) return HK_OK;
+    if (batch >= (1u << 16) || !is_device_ptr(z_out)) return HK_ERR_ARG;
+    if (!is_device_ptr(full_cols))
+        for (size_t k = 0; k < n_full; k++) if (full_cols[k] >= n_v) return HK_ERR_ARG;
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    HK_TRY(L->reserve(al256(4 * n_full) + al256(sizeof(Fr) * n_full * batch) + 4096));
+    const void *cd, *vd;
+    HK_TRY(to_device(L, full_cols, 4 * n_full, &cd));
+    HK_TRY(to_device(L, full_vals, sizeof(Fr) * n_full * batch, &vd));
+    hipLaunchKernelGGL((k_scatter_full_batch<Fr>), dim3((u32)((n_full + 63) / 64), (u32)batch), dim3(64), 0, L->stream,
+                       (const u32*)cd, (const Fr*)vd, (u32)n_full, n_v, (Fr*)z_out);
+    HK_HIP(hipGetLastError());
+    HK_HIP(hipStreamSynchronize(L->stream));
+    return HK_OK;
+}
+
 template <class C>
 hk_status Ops<C>::poseidon_path(hk_ctx* ctx, const void* consts, size_t n_consts, const hk_poseidon_desc* lh,
                                 const hk_poseidon_desc* nh, const void* leaf, const void* siblings, const uint32_t* index,

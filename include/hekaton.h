@@ -274,6 +274,11 @@ hk_status hk_wprog_upload(hk_ctx* ctx, const uint32_t* ops, size_t n_ops, const 
 void      hk_wprog_free(hk_wprog* w);
 hk_status hk_wprog_run(hk_ctx* ctx, const hk_wprog* w, const uint32_t* inputs, size_t batch, const uint32_t* full_cols,
                        const void* full_vals_mont, size_t n_full, void* z_out);
+/* The full-width values alone: z_out[b][full_cols[j]] = full_vals[b][j] for b < batch.  A subcircuit's bit columns do not
+ * depend on the round's challenges, its running evaluations do (distributed-prover/src/subcircuit_circuit.rs:206-231): a
+ * worker may run hk_wprog_run with n_full = 0 while the first round is still in flight and hand these in afterwards. */
+hk_status hk_assignment_scatter(hk_ctx* ctx, const uint32_t* full_cols, const void* full_vals_mont, size_t n_full, size_t batch,
+                                size_t n_v, void* z_out);
 
 /* The Poseidon membership block of a subcircuit's assignment (the witness side of `verify_membership`,
  * distributed-prover/src/subcircuit_circuit.rs:233-252, with the hashes of poseidon_util.rs:26-107): for `batch`

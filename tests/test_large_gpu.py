@@ -284,6 +284,13 @@ def test_witness_generated_on_the_device_equals_the_host_trace(kind, ctx_bn254):
     got = zdev.to_host().reshape(len(ws), -1)
     want = circ.assignment_bytes(ws)
     assert np.array_equal(got, want)
+    # the same assignments in two steps: the program alone first (what a worker can run before the round's challenges
+    # are known), the full-width values afterwards (hk_assignment_scatter)
+    z2 = wp.run(program_inputs(circ, ws), [], [])
+    wp.scatter(cols, vals, z2)
+    ctx_bn254.poseidon_path(device_params(cname, fc), leaves, sibs, idx, circ.n_v, circ.pos_col0, z2)
+    assert np.array_equal(z2.to_host().reshape(len(ws), -1), want)
+    z2.free()
     # a malformed program (operand reference beyond the values defined so far) is refused, not interpreted
     bad = ops.copy()
     k = int(np.nonzero(bad[:, 0] == 2)[0][0])
