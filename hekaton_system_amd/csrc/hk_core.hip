@@ -70,7 +70,13 @@ static presize_fn presize_kernel_for(size_t frame, size_t* actual) {
 }
 
 hk_status scratch_budget_check(const CurveOps* ops, const hipDeviceProp_t& prop, void** presize_out) {
+    // the deepest frame of EVERY curve the library carries, not only this context's: a process that opens a context of the
+    // other curve later (the bench's BLS12-381 leg after its BN254 leg) then finds every queue's ring already at its final
+    // size - no ring ever grows, and the moment the round-3 experiment aborted in (twenty rings wanted at once while the
+    // previous context's were still held) does not arise
     size_t frame = ops->max_private_bytes ? ops->max_private_bytes() : 0;
+    for (const CurveOps* o : {curve_ops_bn254(), curve_ops_bls381()})
+        if (o && o->max_private_bytes && o->max_private_bytes() > frame) frame = o->max_private_bytes();
     size_t prev = g_deepest_frame.load();
     while (frame > prev && !g_deepest_frame.compare_exchange_weak(prev, frame)) {}
     frame = g_deepest_frame.load();
