@@ -22,6 +22,8 @@ template <class P> struct WaveTab;
     static __device__ const unsigned char PRE##_pre_idx[54][8] = PRE##_PRE_IDX;                          \
     static __device__ const unsigned char PRE##_postf[48][PRE##_POSTF_LEN] = PRE##_POSTF;                \
     static __device__ const u32 PRE##_frob[3][6][2][FQP::N] = PRE##_FROB;                                \
+    static __device__ const unsigned char PRE##_cyc_pre_idx[27][4] = PRE##_CYC_PRE_IDX;                  \
+    static __device__ const unsigned char PRE##_cyc_postf[48][PRE##_CYC_POSTF_LEN] = PRE##_CYC_POSTF;    \
     template <> struct WaveTab<FQP> {                                                                    \
         static constexpr int NLEVELS = PRE##_NLEVELS;                                                    \
         static constexpr int POSTF_LEN = PRE##_POSTF_LEN;                                                \
@@ -31,6 +33,12 @@ template <class P> struct WaveTab;
         static __device__ __forceinline__ const unsigned char* pre_idx(u32 l) { return PRE##_pre_idx[l]; } \
         static __device__ __forceinline__ const unsigned char* postf(u32 l) { return PRE##_postf[l]; }   \
         static __device__ __forceinline__ const u32* frob(int k, u32 j, u32 c) { return PRE##_frob[k - 1][j][c]; } \
+        static constexpr int CYC_NLEVELS = PRE##_CYC_NLEVELS;                                            \
+        static constexpr int CYC_POSTF_LEN = PRE##_CYC_POSTF_LEN;                                        \
+        static constexpr int cyc_n_add(int l) { constexpr int t[PRE##_CYC_NLEVELS] = PRE##_CYC_POSTF_ADD; return t[l]; } \
+        static constexpr int cyc_n_sub(int l) { constexpr int t[PRE##_CYC_NLEVELS] = PRE##_CYC_POSTF_SUB; return t[l]; } \
+        static __device__ __forceinline__ const unsigned char* cyc_pre_idx(u32 l) { return PRE##_cyc_pre_idx[l]; } \
+        static __device__ __forceinline__ const unsigned char* cyc_postf(u32 l) { return PRE##_cyc_postf[l]; } \
     };
 HK_DEFINE_WAVETAB(Bn254FqP, HK_BN254_WV)
 HK_DEFINE_WAVETAB(Bls381FqP, HK_BLS12_381_WV)
@@ -45,6 +53,8 @@ struct alignas(16) WaveArea {
     Fp<P> part[48];
     alignas(8) unsigned char pre_idx[54][8];
     alignas(4) unsigned char postf[48][WaveTab<P>::POSTF_LEN];
+    alignas(4) unsigned char cyc_pre_idx[28][4];                                   // squaring in the cyclotomic subgroup
+    alignas(4) unsigned char cyc_postf[48][WaveTab<P>::CYC_POSTF_LEN];
 };
 
 template <class P>
@@ -64,6 +74,12 @@ struct WaveF12 {
         if (lane < 48) {
             const unsigned char* ps = T::postf(lane);
             for (int j = 0; j < T::POSTF_LEN; j++) w->postf[lane][j] = ps[j];
+            const unsigned char* cs = T::cyc_postf(lane);
+            for (int j = 0; j < T::CYC_POSTF_LEN; j++) w->cyc_postf[lane][j] = cs[j];
+        }
+        if (lane < 27) {
+            const unsigned char* ci = T::cyc_pre_idx(lane);
+            for (int j = 0; j < 4; j++) w->cyc_pre_idx[lane][j] = ci[j];
         }
         if (lane >= 54) w->prod[lane] = Fq::zero();
         sync();
@@ -111,6 +127,50 @@ struct WaveF12 {
         sync();
     }
     static __device__ __forceinline__ void sqr(Fq* dst, const Fq* a, WaveArea<P>* w) { mul(dst, a, a, w); }
+
+    // dst = a^2 for a IN THE CYCLOTOMIC SUBGROUP (everything after the easy part of the final exponentiation, every
+    // element of GT): Granger-Scott, alpha^2 = (3 a^2 - 2 conj(a)) + (3 s c^2 + 2 conj(b)) t + (3 b^2 - 2 conj(c)) t^2 over
+    // Fq4, written with squares only - 27 lanes square the sum of <= 4 coefficients (tables generated and checked against
+    // the plain square on a cyclotomic element by gen_tower_params.py: wave_cyc_forms / wave_cyc_check), the recombination
+    // has 20 (BN254) / 12 (BLS12-381) entries per lane instead of 27 / 16, and there is ONE operand sum of <= 4 terms
+    // instead of two of 8; every output takes -+2 of its own input coefficient (- on the c0 half, + on the c1 half).
+    static __device__ __noinline__ void cyc_sqr(Fq* dst, const Fq* a, WaveArea<P>* w) {
+        u32 lane = threadIdx.x;
+        if (lane < 27) {
+            u32 i0 = *reinterpret_cast<const u32*>(w->cyc_pre_idx[lane]);
+            Fq x = a[i0 & 0xff];
+            HK_UNROLL for (int j = 1; j < 4; j++) x = Fq::add(x, a[(i0 >> (8 * j)) & 0xff]);
+            w->prod[lane] = Fq::mul(x, x);
+        }
+        sync();
+        if (lane < 48) {
+            u32 codes[T::CYC_POSTF_LEN / 4];
+            const u32* row = reinterpret_cast<const u32*>(w->cyc_postf[lane]);
+            HK_UNROLL for (int k = 0; k < T::CYC_POSTF_LEN / 4; k++) codes[k] = row[k];
+            Fq acc = Fq::zero();
+            int pos = 0;
+            HK_UNROLL for (int lev = 0; lev < T::CYC_NLEVELS; lev++) {
+                if (lev) acc = Fq::dbl(acc);
+                HK_UNROLL for (int e = 0; e < T::cyc_n_add(lev); e++, pos++)
+                    acc = Fq::add(acc, w->prod[(codes[pos >> 2] >> (8 * (pos & 3))) & 0xff]);
+                HK_UNROLL for (int e = 0; e < T::cyc_n_sub(lev); e++, pos++)
+                    acc = Fq::sub(acc, w->prod[(codes[pos >> 2] >> (8 * (pos & 3))) & 0xff]);
+            }
+            w->part[lane] = acc;
+        }
+        sync();
+        Fq r;
+        if (lane < 12) {
+            r = Fq::add(Fq::add(w->part[4 * lane], w->part[4 * lane + 1]),
+                        Fq::add(w->part[4 * lane + 2], w->part[4 * lane + 3]));
+            Fq two_a = Fq::dbl(a[lane]);
+            r = lane < 6 ? Fq::sub(r, two_a) : Fq::add(r, two_a);
+        }
+        sync();                                                  // dst may be a
+        if (lane < 12) dst[lane] = r;
+        if (lane == 12) dst[12] = Fq::zero();
+        sync();
+    }
 
     static __device__ __forceinline__ void copy(Fq* dst, const Fq* a) {
         u32 lane = threadIdx.x;
@@ -189,8 +249,8 @@ struct WaveF12 {
         copy(dst, a);
         int top = 63;
         while (!((x >> top) & 1)) top--;
-        for (int bit = top - 1; bit >= 0; bit--) {
-            sqr(dst, dst, w);
+        for (int bit = top - 1; bit >= 0; bit--) {                 // only ever called on the cyclotomic subgroup (hard part)
+            cyc_sqr(dst, dst, w);
             if ((x >> bit) & 1) mul(dst, dst, a, w);
         }
     }
@@ -540,7 +600,7 @@ k_gt_pow_endo(const Fp12<P>* __restrict__ in, const Fr* __restrict__ scalars_mon
             if ((mags[j][b >> 5] >> (b & 31)) & 1u) top = b;
     W::set_one(acc);
     for (int b = top; b >= 0; b--) {
-        W::sqr(acc, acc, w);
+        W::cyc_sqr(acc, acc, w);                                 // GT lies in the cyclotomic subgroup
         u32 m = 0;
         for (int j = 0; j < 4; j++) m |= ((mags[j][b >> 5] >> (b & 31)) & 1u) << j;
         if (m) W::mul(acc, acc, tab + m * WV_SLOT, w);
