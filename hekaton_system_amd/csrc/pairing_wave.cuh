@@ -50,7 +50,6 @@ constexpr int WV_SLOT = 13;            // Fq per value: 12 coefficients + one ze
 template <class P>
 struct alignas(16) WaveArea {
     Fp<P> prod[64];
-    Fp<P> part[48];
     alignas(8) unsigned char pre_idx[54][8];
     alignas(4) unsigned char postf[48][WaveTab<P>::POSTF_LEN];
     alignas(4) unsigned char cyc_pre_idx[28][4];                                   // squaring in the cyclotomic subgroup
@@ -85,6 +84,18 @@ struct WaveF12 {
         sync();
     }
 
+    // sum of a value over the four lanes of a quad, left in all four (two DPP quad_perm exchanges; no LDS, no barrier)
+    template <int CTRL>
+    static __device__ __forceinline__ Fq quad_perm(const Fq& v) {
+        Fq r;
+        HK_UNROLL for (int i = 0; i < P::N; i++) r.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)v.v[i], CTRL, 0xf, 0xf, true);
+        return r;
+    }
+    static __device__ __forceinline__ Fq quad_sum(const Fq& v) {
+        Fq t = Fq::add(v, quad_perm<0xB1>(v));                   // quad_perm [1, 0, 3, 2]
+        return Fq::add(t, quad_perm<0x4E>(t));                   // quad_perm [2, 3, 0, 1]
+    }
+
     // dst = a * b   (dst may alias a or b).  Straight-line code: every lane sums 8 (zero-padded) coefficients per
     // operand and, per bit level of the multipliers, a fixed number of products to add and to subtract (padded with a
     // zero product) - the trip counts the SIMD ran anyway, without the ~60 dependent LDS round trips of parsing a list.
@@ -102,6 +113,7 @@ struct WaveF12 {
             w->prod[lane] = Fq::mul(x, y);
         }
         sync();
+        Fq part = Fq::zero();
         if (lane < 48) {
             u32 codes[T::POSTF_LEN / 4];
             const u32* row = reinterpret_cast<const u32*>(w->postf[lane]);
@@ -115,15 +127,13 @@ struct WaveF12 {
                 HK_UNROLL for (int e = 0; e < T::n_sub(lev); e++, pos++)
                     acc = Fq::sub(acc, w->prod[(codes[pos >> 2] >> (8 * (pos & 3))) & 0xff]);
             }
-            w->part[lane] = acc;
+            part = acc;
         }
-        sync();
-        if (lane < 12) {
-            Fq r = Fq::add(Fq::add(w->part[4 * lane], w->part[4 * lane + 1]),
-                           Fq::add(w->part[4 * lane + 2], w->part[4 * lane + 3]));
-            dst[lane] = r;
-        }
-        if (lane == 12) dst[12] = Fq::zero();
+        // the four partial sums of an output sit on the lanes of one quad: summed by DPP, written by the quad's first lane
+        // (no lane reads a or b after the barrier above, so dst may alias them)
+        Fq r = quad_sum(part);
+        if (lane < 48 && (lane & 3u) == 0) dst[lane >> 2] = r;
+        if (lane == 48) dst[12] = Fq::zero();
         sync();
     }
     static __device__ __forceinline__ void sqr(Fq* dst, const Fq* a, WaveArea<P>* w) { mul(dst, a, a, w); }
@@ -143,6 +153,7 @@ struct WaveF12 {
             w->prod[lane] = Fq::mul(x, x);
         }
         sync();
+        Fq part = Fq::zero();
         if (lane < 48) {
             u32 codes[T::CYC_POSTF_LEN / 4];
             const u32* row = reinterpret_cast<const u32*>(w->cyc_postf[lane]);
@@ -156,19 +167,15 @@ struct WaveF12 {
                 HK_UNROLL for (int e = 0; e < T::cyc_n_sub(lev); e++, pos++)
                     acc = Fq::sub(acc, w->prod[(codes[pos >> 2] >> (8 * (pos & 3))) & 0xff]);
             }
-            w->part[lane] = acc;
+            part = acc;
         }
-        sync();
-        Fq r;
-        if (lane < 12) {
-            r = Fq::add(Fq::add(w->part[4 * lane], w->part[4 * lane + 1]),
-                        Fq::add(w->part[4 * lane + 2], w->part[4 * lane + 3]));
-            Fq two_a = Fq::dbl(a[lane]);
-            r = lane < 6 ? Fq::sub(r, two_a) : Fq::add(r, two_a);
+        Fq r = quad_sum(part);
+        if (lane < 48 && (lane & 3u) == 0) {                     // output k = lane / 4: only this lane touches slot k from here on
+            u32 k = lane >> 2;
+            Fq two_a = Fq::dbl(a[k]);
+            dst[k] = k < 6 ? Fq::sub(r, two_a) : Fq::add(r, two_a);
         }
-        sync();                                                  // dst may be a
-        if (lane < 12) dst[lane] = r;
-        if (lane == 12) dst[12] = Fq::zero();
+        if (lane == 48) dst[12] = Fq::zero();
         sync();
     }
 
