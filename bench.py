@@ -65,6 +65,8 @@ def parse():
                     help="skip the `with_synthesis` object (N = 1 only): real SHA-256 big-merkle subcircuits whose "
                          "assignments are generated INSIDE the timed step - the reference's timer includes synthesis "
                          "(node.rs:589-596, prover.rs:70-75)")
+    ap.add_argument("--no-batch-commit", action="store_true",
+                    help="round 1 as one hk_commit per subcircuit instead of one hk_commit_batch per key class (A/B)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing checks of the timed proofs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the post-timing aggregation of the last step's proofs")
     ap.add_argument("--witness-gen", action="store_true",
@@ -259,7 +261,7 @@ class Job:
                              wprog=self.ctx.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs),
                              zbig=capi.DeviceBuffer(self.ctx, len(members) * circ.n_v * self.ctx.fr_bytes))
             self.classes[rep] = dict(circ=circ, pk=pk, td=td, dpk=dpk, host=host, zs=zs, w0s=w0s, seeds=seeds,
-                                     members=members, matrices=pk.matrices, **extra)
+                                     members=members, matrices=pk.matrices, w0_host=[wb for _ws, _zb, wb in assigns], **extra)
             log("rank %d: %s class %d (%d subcircuits of this shard): key + %d assignments resident, %.1f s" % (
                 rank, curve, rep, len(members), len(zs), time.time() - t0))
         prepared["classes"] = None                   # the host copies are no longer needed
@@ -292,6 +294,19 @@ class Job:
         self.wg_s = 0.0
         self.last_records = None
         self.prev_records = None
+
+    # -- round 1 for every subcircuit of a key class in one call (hk_commit_batch) ------------------------
+    def _stage0_class(self, c):
+        from hekaton_system_amd.worker import Stage0Response
+        import numpy as np
+        members = c["members"]
+        if "w0_rows" not in c:              # the requests' stage-0 witnesses row after row: input data, laid out once
+            rows = np.concatenate([np.asarray(c["w0_host"][self.assign_of[i]], np.uint8).reshape(-1) for i in members])
+            c["w0_rows"] = rows if self.args.host_inputs else self.capi.DeviceBuffer.from_host(self.ctx, rows)
+            c["kappa_rows"] = np.concatenate([np.asarray(self.rand[i]["kappa_b"], np.uint8).reshape(-1) for i in members])
+        coms = c["dpk"].commit_batch(0, c["w0_rows"], c["kappa_rows"], c["circ"].n0, len(members))
+        t = self.ctx.last_timings()
+        return [(i, Stage0Response(i, coms[k], self.rand[i]["com_seed"]).to_record(), t) for k, i in enumerate(members)]
 
     # -- the two rounds of one subcircuit ----------------------------------------------------------------
     def _stage0(self, i):
@@ -381,7 +396,11 @@ class Job:
         g1b = self.ctx.g1_bytes
         if self.args.witness_gen:
             self._start_witness_programs()
-        r0 = list(self.pool.map(self._stage0, self.shard))
+        if self.args.no_batch_commit:
+            r0 = list(self.pool.map(self._stage0, self.shard))
+        else:                                # one call per key class, classes side by side
+            by_i = {i: (rec, t) for part in self.pool.map(self._stage0_class, list(self.classes.values())) for i, rec, t in part}
+            r0 = [by_i[i] for i in self.shard]
         all0 = self._gather([r for r, _ in r0])                           # node.rs:500-506
         assert len(all0) == self.n_total
         coms = [r[8:8 + g1b] for r, _ in r0]
@@ -443,7 +462,7 @@ class Job:
     def close(self):
         self.pool.shutdown()
         for c in self.classes.values():
-            for b in c["zs"] + c["w0s"] + ([c["zbig"]] if c.get("zbig") else []):
+            for b in c["zs"] + c["w0s"] + ([c["zbig"]] if c.get("zbig") else []) + ([c["w0_rows"]] if c.get("w0_rows") is not None else []):
                 if isinstance(b, self.capi.DeviceBuffer):
                     b.free()
             c["dpk"].free()
@@ -556,7 +575,11 @@ def roofline_of(job, curve):
     # leaves room for the "+2^15 per window" constant inside 256 bits, so there is no 17th digit
     nwin = 16
     terms = [m - 1, circ.n_v - 1, circ.n_v - 1, n1, circ.n0]
-    alg_bytes = sum(terms) * (32 + g1) / len(terms)
+    # launches of the kernel per subcircuit in the timed steps: H, A, B1, L of stage 1, + the stage-0 commitment's unless
+    # round 1 ran as hk_commit_batch (short stages take no bucket pass there)
+    per_sub = int(round(np.sum(job.accum_n) / max(1, len(job.accum_ms)))) if job.accum_ms else 5
+    per_sub = min(max(per_sub, 1), 5)
+    alg_bytes = sum(terms[:per_sub]) * (32 + g1) / per_sub
     avg_ms = float(np.sum(job.accum_ms) / max(1, np.sum(job.accum_n))) if job.accum_ms else float("nan")
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     h_ms = float(np.mean(job.accum_h)) if job.accum_h else float("nan")
@@ -590,8 +613,8 @@ def roofline_of(job, curve):
     mad_only = VMAD_RATE_TOPS * 1e3 / (2 * (fq_limbs ** 2))
     return m, {
         "bound": "hbm",
-        "kernel": "k_msm_accum0<Fp<%s>> (bucket accumulation; avg over its 5 launches per subcircuit)" % (
-            "Bn254FqP" if curve == "bn254" else "Bls381FqP"),
+        "kernel": "k_msm_accum0<Fp<%s>> (bucket accumulation; avg over its %d launches per subcircuit)" % (
+            "Bn254FqP" if curve == "bn254" else "Bls381FqP", per_sub),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_source, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
         "proofs_in_flight": job.args.threads, "alone": alone,

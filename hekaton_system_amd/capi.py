@@ -67,7 +67,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_points_fold_many_g1", "hk_points_fold_many_g2", "hk_pairing_pairs", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_fq12_pow", "hk_poseidon_path", "hk_assignment_scatter"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_points_fold_many_g1", "hk_points_fold_many_g2", "hk_pairing_pairs", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_fq12_pow", "hk_poseidon_path", "hk_assignment_scatter", "hk_commit_batch"]
 
 _lib = None
 
@@ -139,6 +139,7 @@ def load():
     lib.hk_pk_free.argtypes = [vp]
     lib.hk_pk_free.restype = None
     lib.hk_commit.argtypes = [vp, vp, sz, vp, sz, vp, vp]
+    lib.hk_commit_batch.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
     lib.hk_prove.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp]
     _lib = lib
     return lib
@@ -602,6 +603,17 @@ class DevicePk:
         out = np.zeros(ctx.g1_bytes, dtype=np.uint8)
         check(ctx.lib.hk_commit(ctx.handle, self.handle, stage, ptr(w_stage) if n else None, n,
                                 kappa.ctypes.data, out.ctypes.data), "hk_commit")
+        return out
+
+    def commit_batch(self, stage, w_rows, kappas, n, batch):
+        """hk_commit_batch: the stage commitments of `batch` subcircuits of this key's class in one call.  w_rows: their
+        stage witnesses row after row (batch x n Fr Montgomery; uint8 array or DeviceBuffer); kappas: batch Fr Montgomery
+        (uint8 array).  Returns (batch, g1_bytes) uint8."""
+        ctx = self.ctx
+        kap = np.ascontiguousarray(kappas, dtype=np.uint8)
+        out = np.zeros((batch, ctx.g1_bytes), dtype=np.uint8)
+        check(ctx.lib.hk_commit_batch(ctx.handle, self.handle, stage, ptr(w_rows) if n else None, n, kap.ctypes.data, batch,
+                                      out.ctypes.data), "hk_commit_batch")
         return out
 
     def prove(self, z, r, s, kappas, n_v=None):

@@ -121,6 +121,7 @@ struct Ops {
     static hk_status pk_upload(hk_ctx*, const hk_pk_desc*, hk_pk**);
     static void pk_free(hk_pk*);
     static hk_status commit(hk_ctx*, const hk_pk*, size_t, const void*, size_t, const void*, void*);
+    static hk_status commit_batch(hk_ctx*, const hk_pk*, size_t, const void*, size_t, const void*, size_t, void*);
     static hk_status prove(hk_ctx*, const hk_pk*, const void*, size_t, const void*, const void*,
                            const void*, size_t, void*, void*, void*);
     static void ctx_release(hk_ctx*);
@@ -166,7 +167,7 @@ struct Ops {
                                    &ctx_release, &fixed_base, &scalar_pairing, &field_convert, &bases_upload,
                                    &bases_free, &msm_bases, &pairing_products,
                                    sizeof(Fp12<typename Fq::Params>), &points_lincomb, &points_fold_g2, &points_fold_g1, &assignment_from_bits, &wprog_upload, &wprog_free, &wprog_run, &gt_pow,
-                                   &max_private_bytes, &poseidon_path, &points_fold_many, &pairing_pairs, &assignment_scatter};
+                                   &max_private_bytes, &poseidon_path, &points_fold_many, &pairing_pairs, &assignment_scatter, &commit_batch};
         return &t;
     }
 };

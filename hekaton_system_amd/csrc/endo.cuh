@@ -400,7 +400,8 @@ template <class P> struct LanesPerValue<Fp2Q<P>> { static constexpr int value = 
 // v.lo[y] / v.pts[y] and writes out[y n ..) (UNIFORM: the same scalar for every vector - the folds of one TIPA round).
 // tab: vectors x split_tab_bytes(n).
 constexpr int FOLD_MAX = 4;
-template <class F> struct SplitVecs { const Affine<F>* lo[FOLD_MAX]; const Affine<F>* pts[FOLD_MAX]; };
+// pts_mod != 0: element i reads pts[i % pts_mod] - one short base set under many scalar vectors (hk_commit_batch)
+template <class F> struct SplitVecs { const Affine<F>* lo[FOLD_MAX]; const Affine<F>* pts[FOLD_MAX]; u32 pts_mod; };
 
 template <class Fr, class F, bool UNIFORM>
 __global__ void __launch_bounds__(64)
@@ -442,7 +443,7 @@ k_points_mul_split(SplitVecs<F> v, const Fr* __restrict__ scalars, u32 neg_all, 
             negate = (neg >> j) & 1u;
         }
         split_bias<ND>(m);
-        Affine<F> q = ld_vec(&pts[i]);
+        Affine<F> q = ld_vec(&pts[v.pts_mod ? i % v.pts_mod : i]);
         if (!q.is_inf()) {
             HK_NOUNROLL for (u32 k = 0; k < j; k++) q = EndoOf<F>::apply(q);
             if (negate) q.y = F::neg(q.y);
@@ -501,6 +502,22 @@ k_points_sum(const XYZZ<F>* __restrict__ in, u32 n, XYZZ<F>* __restrict__ out) {
         __syncthreads();
     }
     if (threadIdx.x == 0) st_vec(out, sh[0]);
+}
+// out[g] = sum of in[g * seg .. (g + 1) * seg): one 64-lane workgroup per segment (the commitments of hk_commit_batch)
+template <class F>
+__global__ void __launch_bounds__(64)
+k_points_sum_seg(const XYZZ<F>* __restrict__ in, u32 seg, XYZZ<F>* __restrict__ out) {
+    __shared__ XYZZ<F> sh[64];
+    const XYZZ<F>* src = in + (size_t)blockIdx.x * seg;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    HK_NOUNROLL for (u32 i = threadIdx.x; i < seg; i += 64) acc = ec_add_ni(acc, ld_vec(&src[i]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    HK_NOUNROLL for (u32 off = 32; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { XYZZ<F> t = ec_add_ni(sh[threadIdx.x], sh[threadIdx.x + off]); sh[threadIdx.x] = t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_vec(&out[blockIdx.x], sh[0]);
 }
 #endif
 

@@ -498,6 +498,11 @@ hk_status hk_commit(hk_ctx* ctx, const hk_pk* pk, size_t stage, const void* w, s
     if (!ctx || !pk || !kappa || !out) return HK_ERR_ARG;
     return ctx->ops->commit(ctx, pk, stage, w, n, kappa, out);
 }
+hk_status hk_commit_batch(hk_ctx* ctx, const hk_pk* pk, size_t stage, const void* w, size_t n, const void* kappas, size_t batch,
+                          void* out) {
+    if (!ctx || !pk || (batch && (!kappas || !out))) return HK_ERR_ARG;
+    return ctx->ops->commit_batch(ctx, pk, stage, w, n, kappas, batch, out);
+}
 hk_status hk_prove(hk_ctx* ctx, const hk_pk* pk, const void* z, size_t n_v, const void* r, const void* s,
                    const void* kappas, size_t n_kappas, void* a, void* b, void* c) {
     if (!ctx || !pk || !z || !r || !s || !a || !b || !c) return HK_ERR_ARG;

@@ -138,6 +138,8 @@ struct CurveOps {
                                const uint32_t* pair_lhs, const uint32_t* pair_rhs, size_t n_pairs, size_t n, void* out);
     hk_status (*assignment_scatter)(hk_ctx*, const uint32_t* full_cols, const void* full_vals, size_t n_full, size_t batch,
                                     size_t n_v, void* z_out);
+    hk_status (*commit_batch)(hk_ctx*, const hk_pk*, size_t stage, const void* w, size_t n, const void* kappas, size_t batch,
+                              void* out);
 };
 const CurveOps* curve_ops_bn254();
 const CurveOps* curve_ops_bls381();

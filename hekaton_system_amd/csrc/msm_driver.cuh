@@ -69,6 +69,8 @@ struct MsmRun {
     // a short one-off MSM without tables (n K <= SPLIT_MAX_LANES): element-wise products + one workgroup's sum; result: 1 XYZZ
     static hk_status small_msm(hipStream_t s, const Affine<F>* bases, const void* scalars, int mont, u32 n, XYZZ<F>* tab,
                                XYZZ<F>* xy, XYZZ<F>* result);
+    static hk_status small_msm_rows(hipStream_t s, const Affine<F>* bases, const void* scalars, u32 seg, u32 batch, XYZZ<F>* tab,
+                                    XYZZ<F>* xy, XYZZ<F>* result);
     // largest private-memory ("scratch") frame per lane among this flavour's kernels, from the loaded code object
     // (hipFuncGetAttributes): what sizes a hardware queue's scratch ring
     static size_t max_private_bytes();

@@ -131,7 +131,7 @@ size_t MsmRun<F>::max_private_bytes() {
                         (const void*)k_msm_reduce_fused<F>, (const void*)k_msm_bucket_reduce<F>,
                         (const void*)k_msm_window_sum<F>, (const void*)k_msm_final<F>, (const void*)k_to_affine<F>,
                         (const void*)k_msm_build_tables<F>, (const void*)k_batch_affine<F>, (const void*)k_fb_table<F>,
-                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>, (const void*)k_points_fold_endo<Fr, F>, (const void*)k_points_mul_split<Fr, F, true>, (const void*)k_points_mul_split<Fr, F, false>, (const void*)k_points_sum<F>,
+                        (const void*)k_fb_mul<Fr, F>, (const void*)k_scalar_mul_each<Fr, F>, (const void*)k_scalar_mul_endo<Fr, F>, (const void*)k_points_fold_endo<Fr, F>, (const void*)k_points_mul_split<Fr, F, true>, (const void*)k_points_mul_split<Fr, F, false>, (const void*)k_points_sum<F>, (const void*)k_points_sum_seg<F>,
                         (const void*)k_points_lincomb<Fr, F>};
     size_t m = 0;
     for (const void* k : ks) { size_t b = hk_private_bytes_of(k); if (b > m) m = b; }
@@ -176,6 +176,7 @@ static inline void launch_mul_split(hipStream_t s, const SplitVecs<Fp2<P>>& v, u
         typedef Fp2Q<P> Q;                                    // same memory layout as Fp2<P>
         SplitVecs<Q> vq;
         for (int y = 0; y < FOLD_MAX; y++) { vq.lo[y] = (const Affine<Q>*)v.lo[y]; vq.pts[y] = (const Affine<Q>*)v.pts[y]; }
+        vq.pts_mod = v.pts_mod;
         hipLaunchKernelGGL((k_points_mul_split<Fr, Q, UNIFORM>), dim3((lanes * 4 + 63) / 64, k), dim3(64), 0, s, vq, scalars,
                            neg_mask, n, E, (Jac<Q>*)tab, (XYZZ<Q>*)xy, scalars_mont);
     } else {
@@ -228,6 +229,24 @@ hk_status MsmRun<F>::small_msm(hipStream_t s, const Affine<F>* bases, const void
     v.pts[0] = bases;
     launch_mul_split<Fr, typename F::Params, false>(s, v, 1u, (const Fr*)scalars, 0u, n, E, reinterpret_cast<Jac<F>*>(tab), xy, mont ? 1 : 0);
     hipLaunchKernelGGL((k_points_sum<F>), dim3(1), dim3(PointsSum<F>::THREADS), 0, s, (const XYZZ<F>*)xy, n, result);
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
+// batch x seg element-wise products over ONE base set of seg points (scalars: [batch][seg] Montgomery), summed per row:
+// result[b] = sum_t scalars[b][t] * bases[t] - the stage commitments of every subcircuit of a key class in one launch
+template <class F>
+hk_status MsmRun<F>::small_msm_rows(hipStream_t s, const Affine<F>* bases, const void* scalars, u32 seg, u32 batch, XYZZ<F>* tab,
+                                    XYZZ<F>* xy, XYZZ<F>* result) {
+    typedef typename ScalarOf<F>::type Fr;
+    size_t n = (size_t)seg * batch;
+    if (n == 0 || n * EndoOf<F>::K > SPLIT_MAX_LANES) return HK_ERR_ARG;
+    static const auto E = EndoOf<F>::split();
+    SplitVecs<F> v = {};
+    v.pts[0] = bases;
+    v.pts_mod = seg;
+    launch_mul_split<Fr, typename F::Params, false>(s, v, 1u, (const Fr*)scalars, 0u, (u32)n, E, reinterpret_cast<Jac<F>*>(tab), xy, 1);
+    hipLaunchKernelGGL((k_points_sum_seg<F>), dim3(batch), dim3(64), 0, s, (const XYZZ<F>*)xy, seg, result);
     HK_HIP(hipGetLastError());
     return HK_OK;
 }

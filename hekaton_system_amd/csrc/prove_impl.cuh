@@ -1403,6 +1403,57 @@ hk_status Ops<C>::commit(hk_ctx* ctx, const hk_pk* h, size_t stage, const void* 
     return HK_OK;
 }
 
+// `batch` commitments under one key and stage.  Short stages (batch (n + 1) K <= SPLIT_MAX_LANES: the 16 stage-0 witnesses
+// of a big-merkle subcircuit) run as ONE set of launches - every term an element-wise product over the endomorphism on its
+// own lanes, one workgroup's sum per commitment, one normalisation - instead of `batch` bucket passes of ten tiny launches
+// each; longer stages fall back to hk_commit per row.
+template <class C>
+hk_status Ops<C>::commit_batch(hk_ctx* ctx, const hk_pk* h, size_t stage, const void* w, size_t n, const void* kappas,
+                               size_t batch, void* out) {
+    if (h->ctx != ctx) return HK_ERR_ARG;
+    PkImpl<C>* pk = (PkImpl<C>*)h->impl;
+    if (stage >= pk->n_stages) return HK_ERR_ARG;
+    if (n + 1 != pk->ck_n[stage]) return HK_ERR_LEN;
+    if (batch == 0) return HK_OK;
+    if ((n && !w) || !kappas || !out) return HK_ERR_ARG;
+    const size_t seg = n + 1, tot = seg * batch;
+    if (tot * EndoOf<Fq>::K > SPLIT_MAX_LANES || is_device_ptr(kappas) || getenv("HK_MSM_NO_SMALL")) {
+        if (is_device_ptr(kappas) || is_device_ptr(out)) return HK_ERR_ARG;
+        for (size_t b = 0; b < batch; b++)
+            HK_TRY(commit(ctx, h, stage, n ? (const char*)w + b * n * sizeof(Fr) : nullptr, n, (const char*)kappas + b * sizeof(Fr),
+                          (char*)out + b * sizeof(Affine<Fq>)));
+        return HK_OK;
+    }
+    LaneGuard g(ctx);
+    Lane* L = g.lane;
+    if (!L) return HK_ERR_DEVICE;
+    size_t need = al256(tot * sizeof(Fr)) + al256(tot * sizeof(XYZZ<Fq>)) + al256(endo_tab_bytes<Fq>(tot)) +
+                  al256(batch * sizeof(XYZZ<Fq>)) + al256(batch * sizeof(Fq)) + al256(batch * sizeof(Affine<Fq>)) + 8192;
+    HK_TRY(L->reserve(need));
+    hipStream_t s = L->stream;
+    bool prof = ctx->profiling;
+    if (prof) HK_HIP(hipEventRecord(L->ev[0], s));
+    Fr* sc = L->alloc_n<Fr>(tot);                              // [batch][n + 1]: a row's witnesses, then its kappa
+    XYZZ<Fq>* xy = L->alloc_n<XYZZ<Fq>>(tot);
+    XYZZ<Fq>* tab = (XYZZ<Fq>*)L->alloc_n<unsigned char>(endo_tab_bytes<Fq>(tot));
+    XYZZ<Fq>* res = L->alloc_n<XYZZ<Fq>>(batch);
+    Fq* pref = L->alloc_n<Fq>(batch);
+    Affine<Fq>* aff = L->alloc_n<Affine<Fq>>(batch);
+    if (!sc || !xy || !tab || !res || !pref || !aff) return HK_ERR_NOMEM;
+    if (n) HK_HIP(hipMemcpy2DAsync(sc, seg * sizeof(Fr), w, n * sizeof(Fr), n * sizeof(Fr), batch, h2d_kind(w), s));
+    HK_HIP(hipMemcpy2DAsync(sc + n, seg * sizeof(Fr), kappas, sizeof(Fr), sizeof(Fr), batch, hipMemcpyHostToDevice, s));
+    HK_TRY(MsmRun<Fq>::small_msm_rows(s, pk->ck_tab[stage], sc, (u32)seg, (u32)batch, tab, xy, res));   // group 0 of the table
+    HK_TRY(MsmRun<Fq>::batch_affine(s, res, aff, pref, (u32)batch));
+    HK_HIP(hipMemcpyAsync(out, aff, batch * sizeof(Affine<Fq>), is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    if (prof) HK_HIP(hipEventRecord(L->ev[1], s));
+    HK_HIP(hipStreamSynchronize(s));
+    if (prof) {
+        memset(&L->timings, 0, sizeof(L->timings));
+        L->timings.total_ms = ev_ms(L->ev[0], L->ev[1]);
+    }
+    return HK_OK;
+}
+
 template <class C>
 hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, const void* r_m,
                         const void* s_m, const void* kappas, size_t n_kappas, void* out_a, void* out_b,

@@ -306,6 +306,13 @@ void      hk_pk_free(hk_pk* pk);
 hk_status hk_commit(hk_ctx* ctx, const hk_pk* pk, size_t stage,
                     const void* w_stage_mont, size_t n, const void* kappa_mont,
                     void* com_affine_out);
+/* The same for `batch` subcircuits of one proving-key class in ONE call - what a worker does for the stage-0 requests of the
+ * subcircuits it holds (distributed-prover/src/worker.rs:91-146 under mpi-snark/src/bin/node.rs:500-506: one rayon task per
+ * subcircuit there): com[b] = msm(ck[stage], w[b]) + kappa[b] * last_delta_g.  w_mont [h|d]: batch x n Fr, row after row;
+ * kappas_mont [h]: batch Fr; coms_affine_out [h]: batch G1.  Short stages (the 16 stage-0 witnesses of a big-merkle subcircuit)
+ * run as one set of launches; long ones as `batch` hk_commit calls. */
+hk_status hk_commit_batch(hk_ctx* ctx, const hk_pk* pk, size_t stage, const void* w_mont, size_t n, const void* kappas_mont,
+                          size_t batch, void* coms_affine_out);
 
 /* CPGroth16::prove_last_stage (prover.rs:78-155) followed by CommitmentBuilder::prove's
  * kappa correction (committer.rs:112-114), everything after constraint synthesis:

@@ -254,3 +254,45 @@ def test_key_of_another_context_is_refused(ctx_bn254):
     finally:
         other.close()
         dpk.free()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_commit_batch_equals_one_commit_per_row(cname, ctx_bn254, ctx_bls, monkeypatch):
+    """hk_commit_batch (every subcircuit of a key class in one call: element-wise products over the endomorphism + one sum
+    per commitment for short stages) = hk_commit row by row: random witnesses, an all-zero row, kappa = 0, a batch of one,
+    and a batch too long for the one-launch form (falls back to per-row calls); HK_ERR_LEN for a wrong stage length."""
+    from hekaton_system_amd.cp_groth16 import FrCodec, SeededRng, generate_parameters
+    from hekaton_system_amd.workload import make_config
+    ctx = ctx_bn254 if cname == "bn254" else ctx_bls
+    fc = FrCodec(cname)
+    circ = make_config(cname, "tiny", 1)
+    pk, _td = generate_parameters(circ, cname, SeededRng(b"\x07" * 32), ctx)
+    dpk = pk.upload(ctx)
+    n0, r = circ.n0, fc.r if hasattr(fc, "r") else None
+    rnd = random.Random(3)
+    from hekaton_system_amd.cp_groth16 import CURVE_PARAMS
+    rmod = CURVE_PARAMS[cname]["r"]
+    try:
+        for batch in (1, 5, 64):
+            rows = [[rnd.randrange(rmod) for _ in range(n0)] for _ in range(batch)]
+            kappas = [rnd.randrange(rmod) for _ in range(batch)]
+            if batch > 1:
+                rows[1] = [0] * n0
+                kappas[2 % batch] = 0
+            wb = np.concatenate([np.frombuffer(bytes(fc.enc(rw)), np.uint8) for rw in rows])
+            kb = np.frombuffer(bytes(fc.enc(kappas)), np.uint8)
+            want = np.stack([dpk.commit(0, np.frombuffer(bytes(fc.enc(rows[b])), np.uint8), np.frombuffer(bytes(fc.enc1(kappas[b])), np.uint8), n=n0)
+                             for b in range(batch)])
+            got = dpk.commit_batch(0, wb, kb, n0, batch)
+            assert np.array_equal(got, want), (cname, batch)
+            dev = capi.DeviceBuffer.from_host(ctx, wb)
+            assert np.array_equal(dpk.commit_batch(0, dev, kb, n0, batch), want), (cname, batch, "device rows")
+            dev.free()
+            monkeypatch.setenv("HK_MSM_NO_SMALL", "1")               # the per-row fallback
+            assert np.array_equal(dpk.commit_batch(0, wb, kb, n0, batch), want), (cname, batch, "fallback")
+            monkeypatch.delenv("HK_MSM_NO_SMALL")
+        with pytest.raises(capi.HekatonError) as e:
+            dpk.commit_batch(0, wb, kb, n0 + 1, 2)
+        assert e.value.status == capi.HK_ERR_LEN
+    finally:
+        dpk.free()
