@@ -308,6 +308,10 @@ class Job:
         t = self.ctx.last_timings()
         return [(i, Stage0Response(i, coms[k], self.rand[i]["com_seed"]).to_record(), t) for k, i in enumerate(members)]
 
+    def _stage0_one(self, i):
+        rec, t = self._stage0(i)
+        return [(i, rec, t)]
+
     # -- the two rounds of one subcircuit ----------------------------------------------------------------
     def _stage0(self, i):
         from hekaton_system_amd.worker import Stage0Response
@@ -396,11 +400,13 @@ class Job:
         g1b = self.ctx.g1_bytes
         if self.args.witness_gen:
             self._start_witness_programs()
-        if self.args.no_batch_commit:
-            r0 = list(self.pool.map(self._stage0, self.shard))
-        else:                                # one call per key class, classes side by side
-            by_i = {i: (rec, t) for part in self.pool.map(self._stage0_class, list(self.classes.values())) for i, rec, t in part}
-            r0 = [by_i[i] for i in self.shard]
+        # round 1: key classes with a SHORT stage 0 (big-merkle: 16 witnesses) take one hk_commit_batch call each; long
+        # stages (vm: 217 280 terms, vkd: 8 192) stay one hk_commit per subcircuit, spread over the lanes as before
+        short = lambda c: (c["circ"].n0 + 1) * len(c["members"]) * 2 <= 65536 and not self.args.no_batch_commit
+        jobs = [(self._stage0_class, c) for c in self.classes.values() if short(c)]
+        jobs += [(self._stage0_one, i) for c in self.classes.values() if not short(c) for i in c["members"]]
+        by_i = {i: (rec, t) for part in self.pool.map(lambda j: j[0](j[1]), jobs) for i, rec, t in part}
+        r0 = [by_i[i] for i in self.shard]
         all0 = self._gather([r for r, _ in r0])                           # node.rs:500-506
         assert len(all0) == self.n_total
         coms = [r[8:8 + g1b] for r, _ in r0]
