@@ -5,6 +5,7 @@
 //                                                        tools/export_job.py, one directory per class)
 //   round 1: for every subcircuit, on T worker threads  process_stage0_request_get_cb (worker.rs:91-146):
 //            kappa = Fr::rand(ChaCha12Rng(com_seed)), com = hk_commit(...)            -> Stage0Response
+//            (short stages: one hk_commit_batch per key class; --no-batch-commit for one call per subcircuit)
 //   (the coordinator's step between the rounds is not part of the worker path)
 //   round 2: for every subcircuit                       process_stage1_request_with_cb (worker.rs:150-195):
 //            hk_prove(...) with the SAME kappa re-derived from com_seed (worker.rs:236-241)  -> Stage1Response
@@ -101,6 +102,7 @@ int main(int argc, char** argv) {
     int device = 0;
     bool host_inputs = false;
     bool bls = false;
+    bool batch_commit = true;
     for (int i = 3; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--threads" && i + 1 < argc) threads = (unsigned)atoi(argv[++i]);
@@ -108,6 +110,7 @@ int main(int argc, char** argv) {
         else if (a == "--warmup" && i + 1 < argc) warmup = (unsigned)atoi(argv[++i]);
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--host-inputs") host_inputs = true;
+        else if (a == "--no-batch-commit") batch_commit = false;
         else if (a == "--curve" && i + 1 < argc) { std::string c = argv[++i]; bls = c == "bls12_381"; if (!bls && c != "bn254") { fprintf(stderr, "unknown curve %s\n", c.c_str()); return 2; } }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -168,13 +171,46 @@ int main(int argc, char** argv) {
         }
         double load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load).count();
 
+        // round 1 as one hk_commit_batch per key class where the stage is short (big-merkle: 16 witnesses): the requests'
+        // stage-0 witnesses row after row and their blinders, laid out once (input data, before the timed region)
+        struct ClassRows { std::vector<size_t> members; Bytes rows, kappas; bool batched = false; };
+        std::vector<ClassRows> crow(n_cls);
+        for (size_t i = 0; i < n_sub; i++) crow[subs[i].cls].members.push_back(i);
+        struct Task { size_t cls, sub; bool whole_class; };
+        std::vector<Task> round1;
+        for (size_t c = 0; c < n_cls; c++) {
+            ClassRows& cr = crow[c];
+            KeyClass& kc = *classes[c];
+            cr.batched = batch_commit && !cr.members.empty() && (kc.n0 + 1) * cr.members.size() * 2 <= 65536;
+            if (!cr.batched) { for (size_t i : cr.members) round1.push_back(Task{c, i, false}); continue; }
+            for (size_t i : cr.members) {
+                const Assignment& as = kc.assigns[subs[i].assign];
+                cr.rows.insert(cr.rows.end(), as.host.begin() + kc.pk.n_inst * sz.fr, as.host.begin() + (kc.pk.n_inst + kc.n0) * sz.fr);
+                Bytes kappa = kappa_of(subs[i].com_seed);                                // committer.rs:85
+                cr.kappas.insert(cr.kappas.end(), kappa.begin(), kappa.end());
+            }
+            round1.push_back(Task{c, 0, true});
+        }
         std::vector<Stage0Response> resp0(n_sub);
         std::vector<Stage1Response> resp1(n_sub);
         auto step = [&]() {
             // round 1 (worker.rs:91-146)
-            parallel_for(n_sub, threads, [&](size_t i) {
+            parallel_for(round1.size(), threads, [&](size_t t) {
+                const Task& tk = round1[t];
+                KeyClass& kc = *classes[tk.cls];
+                if (tk.whole_class) {
+                    const ClassRows& cr = crow[tk.cls];
+                    Bytes coms(sz.g1 * cr.members.size());
+                    check(hk_commit_batch(ctx.raw(), kc.pk.device, 0, kc.n0 ? cr.rows.data() : nullptr, kc.n0, cr.kappas.data(),
+                                          cr.members.size(), coms.data()), "hk_commit_batch");
+                    for (size_t k = 0; k < cr.members.size(); k++) {
+                        size_t i = cr.members[k];
+                        resp0[i] = Stage0Response{(uint64_t)i, Bytes(coms.begin() + k * sz.g1, coms.begin() + (k + 1) * sz.g1), subs[i].com_seed};
+                    }
+                    return;
+                }
+                size_t i = tk.sub;
                 const Subcircuit& sc = subs[i];
-                KeyClass& kc = *classes[sc.cls];
                 const Assignment& as = kc.assigns[sc.assign];
                 Bytes kappa = kappa_of(sc.com_seed);                                     // committer.rs:85
                 Bytes com(sz.g1);
