@@ -97,6 +97,39 @@ def process_stage0_request_get_cb(rng, pk, req, circuit):
     return Stage0Response(req.subcircuit_idx, com, com_seed), cb
 
 
+def process_stage0_requests_batch(rngs, pks, reqs, circuits):
+    """The stage-0 pass of a worker over ALL the subcircuits it holds (the loop of mpi-snark/src/bin/node.rs:500-506 around
+    worker.rs:91-146) with the commitments of every proving-key class in one hk_commit_batch call: the same draws from every
+    subcircuit's `rng`, the same responses and commitment builders as process_stage0_request_get_cb request by request.
+    rngs, pks, reqs, circuits: one entry per request.  Returns [(Stage0Response, CommitmentBuilder)] in request order."""
+    from .cp_groth16 import FrCodec
+    import numpy as np
+    prepared, groups = [], {}
+    for k, (rng, pk, req, circuit) in enumerate(zip(rngs, pks, reqs, circuits)):
+        circuit.subcircuit_idx = req.subcircuit_idx
+        com_seed = rng.gen_seed()                               # worker.rs:129
+        cb = CommitmentBuilder.new(circuit, pk)
+        cb.circuit.generate_constraints(cb.cur_stage, cb.cs)    # committer.rs:61: stage-0 synthesis stays on the host
+        w = cb.cs.current_stage_witness_assignment()
+        kappa = ChaCha12Rng(com_seed).fr(cb.cs.r)               # committer.rs:85: the FIRST draw of ChaCha(com_seed)
+        prepared.append((req, cb, com_seed, w, kappa))
+        groups.setdefault(id(pk), (pk, []))[1].append(k)
+    coms = [None] * len(prepared)
+    for pk, members in groups.values():
+        fc = FrCodec(pk.device.ctx.curve)
+        n = len(prepared[members[0]][3])
+        rows = np.concatenate([np.frombuffer(bytes(fc.enc(prepared[k][3])), np.uint8) for k in members]) if n else np.zeros(0, np.uint8)
+        kap = np.frombuffer(bytes(fc.enc([prepared[k][4] for k in members])), np.uint8)
+        out = pk.device.commit_batch(0, rows, kap, n, len(members))
+        for j, k in enumerate(members):
+            coms[k] = out[j].copy()
+    res = []
+    for (req, cb, com_seed, _w, _kappa), com in zip(prepared, coms):
+        cb.cur_stage += 1
+        res.append((Stage0Response(req.subcircuit_idx, com, com_seed), cb))
+    return res
+
+
 def process_stage1_request_with_cb(rng, cb, com, rand, stage1_req):
     """worker.rs:150-195."""
     assert getattr(cb.circuit, "subcircuit_idx", stage1_req.subcircuit_idx) == stage1_req.subcircuit_idx

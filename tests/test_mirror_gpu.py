@@ -120,4 +120,16 @@ def test_worker_two_round_flow(ctx_bn254):
         oproof = og.Proof(cd.g1_from(p.a), cd.g2_from(p.b), cd.g1_from(p.c), [cd.g1_from(d) for d in p.ds])
         assert np.array_equal(p.ds[0], r0.com)
         assert pairing_bn254.verify_proof(vk, oproof, circuits[i].assignment_ints()[1:4])
+    # the stage-0 pass over all three subcircuits with ONE hk_commit_batch call: the same draws, the same responses
+    from hekaton_system_amd.worker import process_stage0_requests_batch
+    fresh = []
+    for i in range(n_sub):
+        c = make_config("bn254", "tiny")
+        c.set_witness_seed(100 + i)
+        fresh.append(c)
+    rng2 = SeededRng(b"\x04" * 32)
+    batch = process_stage0_requests_batch([rng2] * n_sub, [pk] * n_sub, [Stage0Request(i) for i in range(n_sub)], fresh)
+    for (b0, cb), r0 in zip(batch, resp0):
+        assert b0.subcircuit_idx == r0.subcircuit_idx and b0.com_seed == r0.com_seed and np.array_equal(b0.com, r0.com)
+        assert cb.cur_stage == 1
     pk.device.free()
