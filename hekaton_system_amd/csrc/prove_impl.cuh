@@ -1310,8 +1310,8 @@ __global__ void k_finish(const XYZZ<Fq>* __restrict__ res_g1,   // MA, MB1, ML, 
                          const Affine<Fq>* __restrict__ c1, const Affine<Fq2>* __restrict__ c2,
                          const Fr* __restrict__ rs,              // r, s (Montgomery)
                          Affine<Fq>* __restrict__ out_a, Affine<Fq2>* __restrict__ out_b,
-                         Affine<Fq>* __restrict__ out_c) {
-    if (threadIdx.x) return;
+                         Affine<Fq>* __restrict__ out_c, EndoSplit<2> E) {
+    if (blockIdx.x < 2 && threadIdx.x) return;
     if (blockIdx.x == 0) {
         XYZZ<Fq> A = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[0]), ld_vec(&c1[0])), ld_vec(&c1[1]));
         st_vec(out_a, ec_to_affine(A));
@@ -1319,32 +1319,69 @@ __global__ void k_finish(const XYZZ<Fq>* __restrict__ res_g1,   // MA, MB1, ML, 
         XYZZ<Fq2> B = ec_madd_ni(ec_madd_ni(ld_vec(&res_g2[0]), ld_vec(&c2[0])), ld_vec(&c2[1]));
         st_vec(out_b, ec_to_affine(B));
     } else {
-        // C = s*A + r*B1 + ML' + MH.  The two variable-base products share ONE doubling chain (Straus, 2-bit joint
-        // windows over the table i*A + j*B1, i, j < 4): 256 doublings + <= 128 additions instead of two 254-step
-        // double-and-add ladders - this kernel is the tail of every proof's latency.
-        __shared__ XYZZ<Fq> tab[16];
-        XYZZ<Fq> A = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[0]), ld_vec(&c1[0])), ld_vec(&c1[1]));
-        XYZZ<Fq> B1 = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[1]), ld_vec(&c1[2])), ld_vec(&c1[3]));
-        Fr r = Fr::from_mont(fr_load(&rs[0])), s = Fr::from_mont(fr_load(&rs[1]));
-        tab[0] = XYZZ<Fq>::inf();
-        tab[1] = B1;
-        tab[2] = ec_dbl_ni(B1);
-        tab[3] = ec_add_ni(tab[2], B1);
-        HK_NOUNROLL for (int i = 1; i < 4; i++) {
-            XYZZ<Fq> row = i == 1 ? A : ec_add_ni(tab[4 * (i - 1)], A);          // i*A
-            tab[4 * i] = row;
-            HK_NOUNROLL for (int j = 1; j < 4; j++) tab[4 * i + j] = ec_add_ni(tab[4 * i + j - 1], B1);
+        // C = s*A + r*B1 + ML' + MH.  This kernel is the tail of every proof's latency, and its two variable-base products
+        // were one lane's chain of 256 doublings + <= 128 additions (Straus over a joint table: 3 ms).  They now run as
+        // the short element-wise sweeps do (endo.cuh): A and B1 are normalised by lanes 0 and 1, then FOUR lanes take one
+        // GLV half each (s = s0 + s1 lambda on A, r = r0 + r1 lambda on B1: <= 131 bits) with a signed 4-bit window over
+        // 1P .. 8P and a Jacobian chain - 34 digits x (4 doublings + 1 add) - and lane 0 joins the four partial products.
+        __shared__ Affine<Fq> base[2];
+        __shared__ Jac<Fq> tab[4][SPLIT_TABLE];
+        __shared__ Jac<Fq> part[4];
+        const u32 t = threadIdx.x;
+        if (t < 2) {
+            XYZZ<Fq> X = ec_madd_ni(ec_madd_ni(ld_vec(&res_g1[t]), ld_vec(&c1[2 * t])), ld_vec(&c1[2 * t + 1]));   // A | B1
+            base[t] = ec_to_affine(X);
         }
-        XYZZ<Fq> Cc = XYZZ<Fq>::inf();
-        HK_NOUNROLL for (int w = Fr::N * 16 - 1; w >= 0; w--) {
-            Cc = ec_dbl_ni(ec_dbl_ni(Cc));
-            u32 bs = (s.v[w >> 4] >> (2 * (w & 15))) & 3u, br = (r.v[w >> 4] >> (2 * (w & 15))) & 3u;
-            u32 idx = 4 * bs + br;
-            if (idx) Cc = ec_add_ni(Cc, tab[idx]);
+        __syncthreads();
+        if (t < 4) {
+            constexpr int ND = SplitDigits<Fq>::ND;
+            Fr k = Fr::from_mont(fr_load(&rs[(t >> 1) == 0 ? 1 : 0]));          // lanes 0, 1: s (on A);  lanes 2, 3: r (on B1)
+            u32 c[8], mag[2][6];
+            HK_UNROLL for (int l = 0; l < 8; l++) c[l] = l < Fr::N ? k.v[l] : 0u;
+            u32 neg = endo_decompose<2>(c, E, mag);
+            u32 m[6];
+            HK_UNROLL for (int l = 0; l < 6; l++) m[l] = (t & 1u) ? mag[1][l] : mag[0][l];
+            split_bias<ND>(m);
+            Affine<Fq> q = base[t >> 1];
+            Jac<Fq> acc = Jac<Fq>::inf();
+            const bool q_inf = q.is_inf();
+            if (!q_inf) {
+                if (t & 1u) q = EndoOf<Fq>::apply(q);
+                if ((neg >> (t & 1u)) & 1u) q.y = Fq::neg(q.y);
+                Jac<Fq> e = Jac<Fq>::from_affine(q);
+                tab[t][0] = e;
+                HK_NOUNROLL for (int i = 2; i <= SPLIT_TABLE; i++) {
+                    Jac<Fq> prev = (i & 1) ? tab[t][i - 2] : tab[t][i / 2 - 1];
+                    e = (i & 1) ? jac_madd_ni(prev, q) : jac_dbl_ni(prev);
+                    tab[t][i - 1] = e;
+                }
+                HK_NOUNROLL for (int d = ND - 1; d >= 0; d--) {
+                    int dig = split_digit(m, d);
+                    if (dig == 0 && acc.is_inf()) continue;
+                    HK_NOUNROLL for (int r4 = 0; r4 < 4; r4++) acc = jac_dbl_ni(acc);
+                    if (dig != 0) {
+                        Jac<Fq> e2 = tab[t][(dig < 0 ? -dig : dig) - 1];
+                        if (dig < 0) e2.y = Fq::neg(e2.y);
+                        acc = jac_add_ni(acc, e2);
+                    }
+                }
+            }
+            part[t] = acc;
         }
-        Cc = ec_add_ni(Cc, ld_vec(&res_g1[2]));
-        Cc = ec_add_ni(Cc, ld_vec(&res_g1[3]));
-        st_vec(out_c, ec_to_affine(Cc));
+        __syncthreads();
+        if (t == 0) {
+            Jac<Fq> sum = part[0];
+            HK_NOUNROLL for (int i = 1; i < 4; i++) sum = jac_add_ni(sum, part[i]);
+            XYZZ<Fq> Cc = XYZZ<Fq>::inf();
+            if (!sum.is_inf()) {
+                Cc.x = sum.x; Cc.y = sum.y;
+                Cc.zz = Fq::sqr(sum.z);
+                Cc.zzz = Fq::mul(Cc.zz, sum.z);
+            }
+            Cc = ec_add_ni(Cc, ld_vec(&res_g1[2]));
+            Cc = ec_add_ni(Cc, ld_vec(&res_g1[3]));
+            st_vec(out_c, ec_to_affine(Cc));
+        }
     }
 }
 
@@ -1599,8 +1636,9 @@ hk_status Ops<C>::prove(hk_ctx* ctx, const hk_pk* h, const void* z, size_t n_v, 
     HK_HIP(hipStreamWaitEvent(s, ev[7], 0));
     join_guard.joined = true;                                                  // main now depends on every side stream
     if (prof) HK_HIP(hipEventRecord(ev[19], s));                               // all queries done
+    static const EndoSplit<2> endo_g1 = EndoOf<Fq>::split();
     hipLaunchKernelGGL((k_finish<Fr, Fq, Fq2>), dim3(3), dim3(64), 0, s, res1, res2, pk->consts_g1,
-                       pk->consts_g2, small, oa, ob, oa + 1);
+                       pk->consts_g2, small, oa, ob, oa + 1, endo_g1);
     HK_HIP(hipGetLastError());
     HK_HIP(hipMemcpyAsync(out_a, oa, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, s));
     HK_HIP(hipMemcpyAsync(out_b, ob, sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, s));
