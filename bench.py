@@ -564,7 +564,7 @@ def timed_run(job, steps, warmup, barrier):
     return time.time() - t0
 
 
-def roofline_of(job, curve):
+def roofline_of(job, curve, ms_per_proof=None):
     """Dominant kernel = k_msm_accum0<Fq> (bucket accumulation), launched 5 times per subcircuit: H query (m-1 dense
     terms), A / B1 / L queries (n_v-1, n_v-1, n1 terms) and the stage-0 commitment.  Algorithmic bytes per launch =
     terms * (32 + S1) (SURVEY.md §8d "MSM-G1 = n*(32+S1)"), averaged over the same launches whose durations are
@@ -616,6 +616,33 @@ def roofline_of(job, curve):
                  "h_query_ms": ah, "valu_achieved": ap, "valu_frac": ap / VALU_PRODUCT_CEILING[curve],
                  "proof_latency_ms": float(np.mean([t["total_ms"] for t in al]))}
     prods = (m - 1) * nwin * 10 / (h_ms * 1e-3) / 1e9
+    whole = None
+    if ms_per_proof and hasattr(circ, "query_density") and getattr(job, "synthetic", False):
+        # every kernel of a proof shares the chip with seven other proofs' kernels, so a launch's own duration grows
+        # with what runs beside it; the whole step's products over the whole step's time does not have that bias.
+        # Counted (in Fq products; an Fq2 product = 3; an Fr product = (Fr limbs / Fq limbs)^2: 1 on BN254, 4/9 on BLS12-381): one
+        # mixed add (10 products) per non-zero signed digit of a scalar whose base is not the point at infinity -
+        # full-width scalars have 16 digits, a scalar 1 has one, a scalar 0 none -, the butterflies of the quotient
+        # map's six transforms + its element-wise passes, the matrix-vector products.  NOT counted: bucket reductions,
+        # window sums, k_finish, the digit sort (no products) - the fraction is a lower bound
+        da, db = circ.query_density()
+        full = 1.0 - circ.bit_fraction if hasattr(circ, "bit_fraction") else 0.15
+        per_scalar = (1.0 - full) * 0.5 + full * nwin
+        logm = m.bit_length() - 1
+        frw = (ctx.fr_bytes / ctx.fq_bytes) ** 2
+        parts = {"h_query": (m - 1) * nwin * 10.0,
+                 "a_query": (circ.n_v - 1) * da * per_scalar * 10.0,
+                 "b_g1_query": (circ.n_v - 1) * db * per_scalar * 10.0,
+                 "b_g2_query": (circ.n_v - 1) * db * per_scalar * 10.0 * 3.0,
+                 "l_query": n1 * per_scalar * 10.0,
+                 "quotient_map": frw * (6.0 * (m // 2) * logm + 4.0 * m),
+                 "matrix_vector": frw * 6.0 * circ.n_c}
+        tot = sum(parts.values())
+        rate = tot / (ms_per_proof * 1e-3) / 1e9
+        whole = {"products_per_proof": tot, "parts": parts, "ms_per_proof": ms_per_proof, "achieved": rate,
+                 "frac": rate / VALU_PRODUCT_CEILING[curve],
+                 "note": "all counted products of a proof / (step time / proofs per step): a lower bound, reductions and "
+                         "k_finish not counted; expected digit counts of the workload's scalar mixture"}
     mad_only = VMAD_RATE_TOPS * 1e3 / (2 * (fq_limbs ** 2))
     return m, {
         "bound": "hbm",
@@ -632,7 +659,8 @@ def roofline_of(job, curve):
         "valu": {"unit": "G field mults/s", "achieved": prods, "peak": VALU_PRODUCT_CEILING[curve],
                  "frac": prods / VALU_PRODUCT_CEILING[curve], "peak_mad_only": mad_only,
                  "frac_mad_only": prods / mad_only,
-                 "note": "H-query launch: (m-1) scalars x %d signed 16-bit digits x 10 products per mixed add" % nwin}}
+                 "note": "H-query launch: (m-1) scalars x %d signed 16-bit digits x 10 products per mixed add" % nwin,
+                 "whole_step": whole}}
 
 
 def main():
@@ -754,7 +782,7 @@ def main():
             log("rank %d: end-to-end leg failed: %r" % (rank, e))
             e2e = {"error": repr(e)}
     if rank == 0:
-        m, roof = roofline_of(job, args.curve)
+        m, roof = roofline_of(job, args.curve, dt / (args.subcircuits * args.steps) * 1e3)
         nprov = max(1, len(job.accum_ms))
         out = {
             "metric": "subcircuit Groth16 proofs/sec (whole node), big-merkle",
@@ -798,7 +826,7 @@ def main():
                 s2 = max(2, min(args.steps, 4))
                 dt2 = timed_run(j2, s2, 1, barrier)
                 chk2 = None if args.no_verify else j2.verify_last_step()
-                _m2, roof2 = roofline_of(j2, "bls12_381")
+                _m2, roof2 = roofline_of(j2, "bls12_381", dt2 / (args.subcircuits * s2) * 1e3)
                 out["secondary"] = {"curve": "bls12_381", "value": args.subcircuits * s2 / dt2, "unit": "proofs/s",
                                     "steps": s2, "warmup": 1, "ms_per_step": dt2 / s2 * 1e3,
                                     "pk_classes": 1, "timed_proofs_check": chk2,
