@@ -67,7 +67,7 @@ EXPORTS = ["hk_status_str", "hk_version", "hk_ctx_create", "hk_ctx_destroy", "hk
            "hk_dev_upload", "hk_dev_download", "hk_msm_g1", "hk_msm_g2", "hk_ntt", "hk_witness_map",
            "hk_pk_upload", "hk_pk_free", "hk_commit", "hk_prove", "hk_fixed_base_g1", "hk_fixed_base_g2", "hk_scalar_pairing_g1", "hk_scalar_pairing_g2", "hk_field_convert", "hk_bases_upload", "hk_bases_free",
            "hk_msm_bases", "hk_multi_pairing", "hk_pairing_products", "hk_ctx_gt_bytes",
-           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_points_fold_many_g1", "hk_points_fold_many_g2", "hk_pairing_pairs", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_fq12_pow", "hk_poseidon_path", "hk_assignment_scatter", "hk_commit_batch"]
+           "hk_points_lincomb_g1", "hk_points_lincomb_g2", "hk_points_fold_g2", "hk_points_fold_g1", "hk_points_fold_many_g1", "hk_points_fold_many_g2", "hk_pairing_pairs", "hk_keccak_f1600", "hk_assignment_from_bits", "hk_wprog_upload", "hk_wprog_free", "hk_wprog_run", "hk_gt_pow", "hk_fq12_pow", "hk_gt_pow_prod", "hk_poseidon_path", "hk_assignment_scatter", "hk_commit_batch"]
 
 _lib = None
 
@@ -131,6 +131,7 @@ def load():
     if hasattr(lib, "hk_gt_pow"):
         lib.hk_gt_pow.argtypes = [vp, vp, vp, sz, vp]
         lib.hk_fq12_pow.argtypes = [vp, vp, vp, sz, vp]
+        lib.hk_gt_pow_prod.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp]
     lib.hk_poseidon_path.argtypes = [vp, vp, sz, C.POINTER(hk_poseidon_desc), C.POINTER(hk_poseidon_desc), vp, vp, vp, sz, sz,
                                      sz, sz, vp]
     lib.hk_witness_map.argtypes = [vp, C.POINTER(hk_csr), C.POINTER(hk_csr), C.POINTER(hk_csr), sz, sz,
@@ -298,6 +299,17 @@ class Context:
         out = np.zeros_like(gts)
         fn = self.lib.hk_gt_pow if in_gt else self.lib.hk_fq12_pow
         check(fn(self.handle, gts.ctypes.data, scalars.ctypes.data, gts.shape[0], out.ctypes.data), fn.__name__)
+        return out
+
+    def gt_pow_prod(self, gts, scalars, group_len, in_gt=True):
+        """hk_gt_pow_prod: out[g] = prod_j gts[g * group_len + j]^scalars[g * group_len + j] (a verifier's
+        multi-exponentiations).  Returns (n / group_len, gt_bytes) uint8."""
+        gts = np.ascontiguousarray(gts, dtype=np.uint8).reshape(-1, self.gt_bytes)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+        n = gts.shape[0]
+        out = np.zeros((n // max(1, group_len), self.gt_bytes), dtype=np.uint8)
+        check(self.lib.hk_gt_pow_prod(self.handle, gts.ctypes.data, scalars.ctypes.data, n, group_len, 1 if in_gt else 0,
+                                      out.ctypes.data), "hk_gt_pow_prod")
         return out
 
     def multi_pairing(self, g1, g2, n=None):

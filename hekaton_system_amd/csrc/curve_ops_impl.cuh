@@ -145,7 +145,7 @@ struct Ops {
     static hk_status wprog_upload(hk_ctx*, const uint32_t*, size_t, const uint32_t*, size_t, const uint32_t*, size_t, size_t,
                                   size_t, hk_wprog**);
     static void wprog_free(hk_wprog*);
-    static hk_status gt_pow(hk_ctx*, const void*, const void*, size_t, void*, int);
+    static hk_status gt_pow(hk_ctx*, const void*, const void*, size_t, void*, int, size_t);
     static hk_status wprog_run(hk_ctx*, const hk_wprog*, const uint32_t*, size_t, const uint32_t*, const void*, size_t, void*);
 
     static size_t max_private_bytes() {

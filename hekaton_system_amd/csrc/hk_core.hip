@@ -416,11 +416,16 @@ hk_status hk_assignment_from_bits(hk_ctx* ctx, const void* bits, size_t n_v, con
 }
 hk_status hk_gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, size_t n, void* gt_out) {
     if (!ctx || (n && (!gt_in || !scalars_mont || !gt_out))) return HK_ERR_ARG;
-    return ctx->ops->gt_pow(ctx, gt_in, scalars_mont, n, gt_out, 1);
+    return ctx->ops->gt_pow(ctx, gt_in, scalars_mont, n, gt_out, 1, 1);
 }
 hk_status hk_fq12_pow(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, size_t n, void* gt_out) {
     if (!ctx || (n && (!gt_in || !scalars_mont || !gt_out))) return HK_ERR_ARG;
-    return ctx->ops->gt_pow(ctx, gt_in, scalars_mont, n, gt_out, 0);
+    return ctx->ops->gt_pow(ctx, gt_in, scalars_mont, n, gt_out, 0, 1);
+}
+hk_status hk_gt_pow_prod(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, size_t n, size_t group_len, int in_gt,
+                         void* gt_out) {
+    if (!ctx || group_len == 0 || (n && (!gt_in || !scalars_mont || !gt_out))) return HK_ERR_ARG;
+    return ctx->ops->gt_pow(ctx, gt_in, scalars_mont, n, gt_out, in_gt ? 1 : 0, group_len);
 }
 hk_status hk_points_lincomb_g1(hk_ctx* ctx, const void* const* vecs, const void* coeffs_mont, size_t k, size_t n, void* out) {
     if (!ctx || !vecs || !coeffs_mont || (n && !out)) return HK_ERR_ARG;

@@ -125,7 +125,7 @@ struct CurveOps {
     void (*wprog_free)(hk_wprog*);
     hk_status (*wprog_run)(hk_ctx*, const hk_wprog*, const uint32_t* inputs, size_t batch, const uint32_t* full_cols,
                            const void* full_vals, size_t n_full, void* z_out);
-    hk_status (*gt_pow)(hk_ctx*, const void* gt_in, const void* scalars, size_t n, void* gt_out, int in_gt);
+    hk_status (*gt_pow)(hk_ctx*, const void* gt_in, const void* scalars, size_t n, void* gt_out, int in_gt, size_t group_len);
     // largest private-memory frame (bytes per lane) among the curve's kernels: sizes the scratch ring the runtime
     // pins to every hardware queue that ever runs one of them
     size_t (*max_private_bytes)();

@@ -98,6 +98,7 @@ struct PairRun {
     // out[e] = in[e]^scalars[e] (GT powers; device pointers)
     // in_gt: the elements lie in GT (order r) - the exponent is then split along the Frobenius (k_gt_pow_endo)
     static hk_status gt_pow(hipStream_t s, const Fp12<P>* in, const void* scalars_mont, u32 n, Fp12<P>* out, bool in_gt);
+    static hk_status gt_prod(hipStream_t s, const Fp12<P>* in, u32 len, u32 groups, Fp12<P>* out);
 };
 
 }  // namespace hk

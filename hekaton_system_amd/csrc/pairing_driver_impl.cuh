@@ -31,6 +31,17 @@ hk_status PairRun<P>::gt_pow(hipStream_t s, const Fp12<P>* in, const void* scala
     return HK_OK;
 }
 
+// out[g] = prod_{j < len} in[g * len + j]: one wave per group on the wave multiplier (the tree kernel with one group per row)
+template <class P>
+hk_status PairRun<P>::gt_prod(hipStream_t s, const Fp12<P>* in, u32 len, u32 groups, Fp12<P>* out) {
+    if (groups == 0 || len == 0) return HK_OK;
+    size_t lds_tree = sizeof(WaveArea<P>) + 2 * WV_SLOT * sizeof(Fp<P>);
+    hipLaunchKernelGGL((k_pair_tree<P>), dim3(1, groups), dim3(64), lds_tree, s, in, len, len, out);
+    HK_DBG(s, "k_pair_tree (gt_prod)");
+    HK_HIP(hipGetLastError());
+    return HK_OK;
+}
+
 template <class P>
 size_t PairRun<P>::max_private_bytes() {
     const void* ks[] = {(const void*)k_pair_lines<Fp2<P>>, (const void*)k_pair_lines<Fp2Q<P>>, (const void*)k_pair_tree_lines<P>, (const void*)k_pair_tree<P>,

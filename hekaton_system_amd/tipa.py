@@ -206,10 +206,10 @@ class Tipp:
             nxt = pos + m                                                   # the folds go right behind the current vectors
             t2 = time.perf_counter()
             # the three G1 folds share c, the three G2 folds c^-1: one batched call per group, issued together
-            folds = [go(ctx.points_fold_many, 1, [aL, w1L, w2L], [aR, w1R, w2R], c, h, [win(k, nxt, h) for k in (0, 4, 5)]),
-                     go(ctx.points_fold_many, 2, [bL, v1L, v2L], [bR, v1R, v2R], c_inv, h, [win(k, nxt, h) for k in (1, 2, 3)])]
-            for f in folds:
-                f.result()
+            # (the G2 fold is the longer one: it goes out from this thread, the G1 fold beside it from the pool)
+            g1_fold = go(ctx.points_fold_many, 1, [aL, w1L, w2L], [aR, w1R, w2R], c, h, [win(k, nxt, h) for k in (0, 4, 5)])
+            ctx.points_fold_many(2, [bL, v1L, v2L], [bR, v1R, v2R], c_inv, h, [win(k, nxt, h) for k in (1, 2, 3)])
+            g1_fold.result()
             self.round_times.append((m, t1 - t0, t2 - t1, time.perf_counter() - t2))
             m, pos = h, nxt
         a, b, v1, v2, w1, w2 = (win(k, pos, 1).to_host() for k in range(6))
@@ -242,25 +242,26 @@ class Tipp:
         challenges = []
         if len(proof["rounds"]) != n.bit_length() - 1:
             return False
-        # the challenges depend on the proof's messages only, so every GT power of the fold check goes to the GPU in
-        # ONE batched call (hk_gt_pow: one wavefront per power)
-        bases, exps = [], []
+        # the challenges depend on the proof's messages only, so the whole fold check T' = T * prod_k TL_k^(c_k) TR_k^(1/c_k)
+        # (likewise U, Z) goes to the GPU as ONE grouped multi-exponentiation (hk_gt_pow_prod: one wavefront per power, then
+        # one per product)
+        groups = {"T": ([], []), "U": ([], []), "Z": ([], [])}
         for rd in proof["rounds"]:
             tr.absorb(b"round", *(F.encode(rd[k]) for k in ("TL", "UL", "ZL", "TR", "UR", "ZR")))
             c = tr.challenge(b"c")
             c_inv = pow(c, -1, r)
             challenges.append(c)
-            bases += [rd["TL"], rd["UL"], rd["ZL"], rd["TR"], rd["UR"], rd["ZR"]]
-            exps += [c, c, c, c_inv, c_inv, c_inv]
-        if bases:
-            # the proof's GT members are the prover's word: the plain chain (hk_fq12_pow), not the Frobenius split that is
+            for name in "TUZ":
+                groups[name][0].extend((rd[name + "L"], rd[name + "R"]))
+                groups[name][1].extend((c, c_inv))
+        if challenges:
+            # the proof's GT members are the prover's word: the plain chain (in_gt = 0), not the Frobenius split that is
             # only a power for elements of order r
-            pw = ctx.gt_pow(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), fc.enc(exps), in_gt=False)
-            for k in range(0, len(bases), 6):
-                tl, ul, zl, trr, ur, zr = (F.decode(pw[k + j]) for j in range(6))
-                T = F.mul(F.mul(tl, T), trr)
-                U = F.mul(F.mul(ul, U), ur)
-                Z = F.mul(F.mul(zl, Z), zr)
+            bases = groups["T"][0] + groups["U"][0] + groups["Z"][0]
+            exps = groups["T"][1] + groups["U"][1] + groups["Z"][1]
+            pw = ctx.gt_pow_prod(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), fc.enc(exps),
+                                 2 * len(challenges), in_gt=False)
+            T, U, Z = F.mul(F.decode(pw[0]), T), F.mul(F.decode(pw[1]), U), F.mul(F.decode(pw[2]), Z)
         a, b = proof["final_a"], proof["final_b"]
         (v1, v2), (w1, w2) = proof["final_v"], proof["final_w"]
         tr.absorb(b"final", a, b, v1, v2, w1, w2)

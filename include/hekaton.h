@@ -192,6 +192,14 @@ hk_status hk_gt_pow(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, si
 /* The same power for ANY Fq12 elements (the plain 254-step square-and-multiply chain): what a verifier uses on values it
  * has not produced itself - the GT members of a TIPA proof (ark's `PairingOutput` deserialises without a subgroup check). */
 hk_status hk_fq12_pow(hk_ctx* ctx, const void* fq12_in, const void* scalars_mont, size_t n, void* fq12_out);
+/* Grouped multi-exponentiation: gt_out[g] = prod_{j < group_len} gt_in[g * group_len + j]^scalars[g * group_len + j], n a
+ * multiple of group_len, n / group_len <= 65535 groups.  The fold check of the TIPA verifier (ark-ip-proofs `gipa` verify
+ * under distributed-prover/src/aggregation.rs:340): T' = T * prod_k TL_k^(c_k) TR_k^(1/c_k), likewise U and Z - three groups
+ * of 2 log2(N) powers; the powers run one wavefront per element as in hk_gt_pow / hk_fq12_pow (in_gt != 0: the Frobenius
+ * split, elements of GT only; 0: the plain chain, any Fq12 element), then one wavefront per group multiplies them up.
+ * gt_in [h|d]: n elements; scalars_mont [h|d]: n Fr; gt_out [h|d]: n / group_len elements. */
+hk_status hk_gt_pow_prod(hk_ctx* ctx, const void* gt_in, const void* scalars_mont, size_t n, size_t group_len, int in_gt,
+                         void* gt_out);
 
 /* Element-wise linear combination of k <= 8 point vectors: out[i] = sum_j coeffs[j] * vecs[j][i], batch-normalised to
  * affine.  Replaces the aggregator's `prepared_input = s0 + s1*x0 + s2*x1 + s3*x2` (distributed-prover/src/

@@ -113,3 +113,20 @@ def test_gt_pow_matches_the_oracle(cname, ctx_bn254, ctx_bls):
     for k, (b, e) in enumerate(zip(bases2, exps2)):
         assert E.f12_dec(out2[k].tobytes()) == T.f12_flat(T.f12_pow(b, e)), ("plain", k)
     assert np.array_equal(out2[0], out[2])
+    # hk_gt_pow_prod: grouped multi-exponentiation (the fold check of the TIPA verifier) against the product of the single
+    # powers, on both chains; group lengths 1 (= hk_gt_pow), 2, 7 and the whole vector
+    def prod(xs):
+        acc = xs[0]
+        for x in xs[1:]:
+            acc = T.f12_mul(acc, x)
+        return acc
+    single = [T.f12_pow(b, e) for b, e in zip(bases, exps)]
+    for glen in (1, 2, 7, len(exps)):
+        got = ctx.gt_pow_prod(enc(bases), fc.enc(exps), glen)
+        assert got.shape == (len(exps) // glen, ctx.gt_bytes)
+        for k in range(len(exps) // glen):
+            assert E.f12_dec(got[k].tobytes()) == T.f12_flat(prod(single[k * glen:(k + 1) * glen])), (glen, k)
+    got = ctx.gt_pow_prod(enc(bases2), fc.enc(exps2), 3, in_gt=False)
+    assert E.f12_dec(got[0].tobytes()) == T.f12_flat(prod([T.f12_pow(b, e) for b, e in zip(bases2, exps2)]))
+    with pytest.raises(Exception):
+        ctx.gt_pow_prod(enc(bases), fc.enc(exps), 3)              # 14 elements are not a multiple of 3
