@@ -80,28 +80,29 @@ class IppCom:
         terms: [(IppCom, int scalar or None for 1)]."""
         F = terms[0][0].F
         ctx = next((c.ctx for c, _ in terms if c.ctx is not None), None)
-        bases, exps, slots = [], [], []
-        for com, k in terms:
-            parts = [com.t, com.u] + ([com.ip] if com.ip is not None else [])
-            if k is None:
-                slots.append(parts)
-                continue
-            slots.append([len(bases) + j for j in range(len(parts))])
-            bases += parts
-            exps += [k] * len(parts)
-        if bases:
-            if ctx is not None:
-                from .cp_groth16 import FrCodec
-                out = ctx.gt_pow(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), FrCodec(ctx.curve).enc(exps))
-                pw = [F.decode(out[i]) for i in range(len(bases))]
-            else:
-                pw = [F.pow(b, e) for b, e in zip(bases, exps)]
-        acc = None
-        for (com, k), sl in zip(terms, slots):
-            parts = sl if k is None else [pw[i] for i in sl]
-            term = IppCom(F, parts[0], parts[1], parts[2] if len(parts) > 2 else None, ctx)
-            acc = term if acc is None else acc + term
-        return acc
+        has_ip = any(com.ip is not None for com, _ in terms)
+        members = [[com.t, com.u] + ([com.ip] if has_ip else []) for com, _ in terms]       # a missing inner product: 1
+        scalars = [1 if k is None else k for _, k in terms]
+        if ctx is not None:
+            # one grouped multi-exponentiation: a group per member (T, U, inner product), a power per term
+            from .cp_groth16 import FrCodec
+            bases, exps = [], []
+            for j in range(3 if has_ip else 2):
+                for parts, k in zip(members, scalars):
+                    bases.append(parts[j] if parts[j] is not None else F.one)
+                    exps.append(k if parts[j] is not None else 0)
+            out = ctx.gt_pow_prod(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), FrCodec(ctx.curve).enc(exps),
+                                  len(terms))
+            res = [F.decode(out[j]) for j in range(len(out))]
+        else:
+            res = []
+            for j in range(3 if has_ip else 2):
+                acc = F.one
+                for parts, k in zip(members, scalars):
+                    if parts[j] is not None:
+                        acc = F.mul(acc, parts[j] if k == 1 else F.pow(parts[j], k))
+                res.append(acc)
+        return IppCom(F, res[0], res[1], res[2] if has_ip else None, ctx)
 
     def __eq__(self, o):
         return self.t == o.t and self.u == o.u and (self.ip or self.F.one) == (o.ip or self.F.one)
@@ -214,10 +215,10 @@ class AggProvingKey:
             pt.append_serializable(b"D-commitment", com_d.serialize_uncompressed())
             twist = pt.challenge_scalar(b"r-random-fiatshamir", r_mod)
         prepared_input, com_prepared_input = f_in.result(), f_cin.result()
-        tw = [1] * n                                                                                # :224 structured_scalar_power
+        tw = [fc.R % r_mod] * n                               # :224 structured_scalar_power, as Montgomery values R * twist^i
         for i in range(1, n):
             tw[i] = tw[i - 1] * twist % r_mod
-        twb = fc.enc(tw)
+        twb = fc.enc_canon(tw)
         a_r, c_r, d_r, alpha_r, input_r = (f.result() for f in [go(ctx.scalar_pairing, 1, v, twb, n)       # :236-242
                                                                 for v in (a_vals, c_vals, d_vals, self.alpha, prepared_input)])
         f_cross = go(ctx.pairing_products, [a_r, input_r, d_r, c_r], [b_vals, self.h, self.delta0, self.delta1], n)   # :255-263
@@ -247,15 +248,12 @@ class AggProvingKey:
         # ARE the pairings of the twisted components (:255-263) - so it costs 16 GT powers in one batched call instead of
         # another element-wise sweep and another N-pair multi-pairing; the same GT element, bit for bit
         exps = [pow(s, i, r_mod) * pow(t, j, r_mod) % r_mod for i in range(4) for j in range(4)]
-        f_z = go(ctx.gt_pow, np.frombuffer(b"".join(F.encode(z[i][j]) for i in range(4) for j in range(4)), np.uint8),
-                 fc.enc(exps))
+        f_z = go(ctx.gt_pow_prod, np.frombuffer(b"".join(F.encode(z[i][j]) for i in range(4) for j in range(4)), np.uint8),
+                 fc.enc(exps), 16)
         ones = fc.enc([1, 1, 1, 1])
         f_left = go(lambda: ctx.points_lincomb(1, [a_vals] + [f.result() for f in fl], ones, n))
         f_right = go(lambda: ctx.points_lincomb(2, [b_vals] + [f.result() for f in fr], ones, n))
-        pw = f_z.result()
-        z_lr = F.one
-        for k in range(16):
-            z_lr = F.mul(z_lr, F.decode(pw[k]))
+        z_lr = F.decode(f_z.result()[0])
         left, right = f_left.result(), f_right.result()
         com_lr = f_lr.result()
         return dict(size=n, output=z_lr, commitment=com_lr, twist=twist, left=left, right=right, cross_terms=z,

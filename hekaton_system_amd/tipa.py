@@ -95,9 +95,11 @@ class Transcript:
             ctr += 1
 
 
-def ipa_polynomial_coeffs(challenges, r_shift, mod):
-    """pairing_ops.rs `ipa_polynomial`: coefficients of prod_k (1 + challenges[k] (r_shift X)^(2^k)), degree 2^l - 1."""
-    coeffs = [1]
+def ipa_polynomial_coeffs(challenges, r_shift, mod, scale=1):
+    """pairing_ops.rs `ipa_polynomial`: coefficients of prod_k (1 + challenges[k] (r_shift X)^(2^k)), degree 2^l - 1, times
+    `scale` (the Montgomery constant R: quotients of a scaled polynomial come out in Montgomery form with no further
+    product per coefficient)."""
+    coeffs = [scale % mod]
     power = r_shift % mod
     for c in challenges:
         factor = c * power % mod
@@ -139,8 +141,8 @@ class Tipp:
         h = len(buf) // 2
         return buf[:h], buf[h:]
 
-    def _powers(self, x, n):
-        out = [1] * n
+    def _powers(self, x, n, first=1):
+        out = [first % self.r] * n
         for i in range(1, n):
             out[i] = out[i - 1] * x % self.r
         return out
@@ -153,8 +155,10 @@ class Tipp:
         n = srs.n
         g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
         from .capi import DeviceBuffer
+        t_start = time.perf_counter()
         r_inv = pow(twist, -1, r)
-        tw, tw_inv = self._powers(twist, n), self._powers(r_inv, n)
+        # R * twist^i: the Montgomery bytes of the powers with no product per element beyond the power itself
+        twb, twib = fc.enc_canon(self._powers(twist, n, fc.R)), fc.enc_canon(self._powers(r_inv, n, fc.R))
         # The six vectors of the recursion live in HBM from here to the last round (one allocation, carved up front: a
         # vector of m elements is followed by its folds of m/2, m/4, ... elements): a round's calls take windows of it and
         # write the folded halves next to them, nothing is downloaded until the single final elements.
@@ -166,7 +170,6 @@ class Tipp:
             off += 2 * n * sz
         win = lambda k, start, count: arena.view(base[k] + start * sizes[k], count * sizes[k])
         go = self.pool.submit
-        twb, twib = fc.enc(tw), fc.enc(tw_inv)
         # B' = B^(r^i), w' = w^(r^-i): three independent element-wise sweeps, issued together; A, v1, v2 are copied in
         first = [go(ctx.scalar_pairing, 2, B, twb, n, win(1, 0, n)),
                  go(ctx.scalar_pairing, 1, srs.ck.w1, twib, n, win(4, 0, n)),
@@ -182,6 +185,7 @@ class Tipp:
         rounds, challenges = [], []
         self.round_times = []                                               # (m, pairings s, host s, folds s) per round
         m, pos = n, 0                                                       # the current vectors start at element `pos`
+        t_rounds = time.perf_counter()
         while m > 1:
             h = m // 2
             L = lambda k: win(k, pos, h)
@@ -212,6 +216,7 @@ class Tipp:
             g1_fold.result()
             self.round_times.append((m, t1 - t0, t2 - t1, time.perf_counter() - t2))
             m, pos = h, nxt
+        t_open = time.perf_counter()
         a, b, v1, v2, w1, w2 = (win(k, pos, 1).to_host() for k in range(6))
         arena.free()
         tr.absorb(b"final", a, b, v1, v2, w1, w2)
@@ -219,13 +224,14 @@ class Tipp:
         ch_rev = challenges[::-1]
         chi_rev = [pow(c, -1, r) for c in ch_rev]
         # KZG openings of the folded keys (kzg.rs:46-70): quotient polynomials, MSMs over the resident SRS powers
-        fv = ipa_polynomial_coeffs(chi_rev, 1, r)
-        qv = fc.enc(_divide_by_linear(fv, z, r))
-        fw = [0] * n + ipa_polynomial_coeffs(ch_rev, r_inv, r)
-        qw = fc.enc(_divide_by_linear(fw, z, r))
+        fv = ipa_polynomial_coeffs(chi_rev, 1, r, fc.R)                    # R f(X): the quotients are Montgomery values
+        qv = fc.enc_canon(_divide_by_linear(fv, z, r))
+        fw = [0] * n + ipa_polynomial_coeffs(ch_rev, r_inv, r, fc.R)
+        qw = fc.enc_canon(_divide_by_linear(fw, z, r))
         res = srs.resident
         opens = [self.pool.submit(res[k].msm, q) for k, q in (("h_alpha", qv), ("h_beta", qv), ("g_alpha", qw), ("g_beta", qw))]
         ov1, ov2, ow1, ow2 = (f.result() for f in opens)                   # four independent MSMs, issued together
+        self.phase_times = (t_rounds - t_start, t_open - t_rounds, time.perf_counter() - t_open)   # setup, rounds, openings
         proof = dict(rounds=rounds, final_a=a, final_b=b, final_v=(v1, v2), final_w=(w1, w2),
                      open_v=(ov1, ov2), open_w=(ow1, ow2))
         return proof
@@ -259,9 +265,10 @@ class Tipp:
             # only a power for elements of order r
             bases = groups["T"][0] + groups["U"][0] + groups["Z"][0]
             exps = groups["T"][1] + groups["U"][1] + groups["Z"][1]
-            pw = ctx.gt_pow_prod(np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8), fc.enc(exps),
-                                 2 * len(challenges), in_gt=False)
-            T, U, Z = F.mul(F.decode(pw[0]), T), F.mul(F.decode(pw[1]), U), F.mul(F.decode(pw[2]), Z)
+            f_fold = self.pool.submit(ctx.gt_pow_prod, np.frombuffer(b"".join(F.encode(x) for x in bases), np.uint8),
+                                      fc.enc(exps), 2 * len(challenges), False)          # beside the checks below
+        else:
+            f_fold = None
         a, b = proof["final_a"], proof["final_b"]
         (v1, v2), (w1, w2) = proof["final_v"], proof["final_w"]
         tr.absorb(b"final", a, b, v1, v2, w1, w2)
@@ -292,6 +299,9 @@ class Tipp:
         f_v = [go(ctx.pairing_pairs, [vk["g"], l1.result()], [l2.result(), pi], [(0, 0), (1, 1)], 1) for l2, l1, pi in v_checks]
         f_w = [go(ctx.pairing_pairs, [l1.result(), pi], [vk["h"], r2.result()], [(0, 0), (1, 1)], 1) for l1, r2, pi in w_checks]
         pi_ = f_inst.result()
+        if f_fold is not None:
+            pw = f_fold.result()
+            T, U, Z = F.mul(D(pw[0]), T), F.mul(D(pw[1]), U), F.mul(D(pw[2]), Z)
         ok = D(pi_[0]) == Z                                                     # the folded instance: e(a, b) = Z
         ok &= F.mul(D(pi_[1]), D(pi_[2])) == T and F.mul(D(pi_[3]), D(pi_[4])) == U
         for f in f_v + f_w:                                                     # both sides of each KZG check

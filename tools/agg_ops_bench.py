@@ -95,6 +95,7 @@ def main():
         t_verify = time.time() - t0
         assert ok
         print("%-8s %8d %14.1f %14.1f %14.1f" % (curve, n, t_setup * 1e3, t_prove * 1e3, t_verify * 1e3))
+        print("         prove: setup %.1f ms, rounds %.1f ms, openings %.1f ms" % tuple(x * 1e3 for x in T.phase_times))
         print("         rounds (m: pairings / host / folds ms): " + "  ".join(
             "%d: %.1f/%.1f/%.1f" % (m, a * 1e3, b * 1e3, c * 1e3) for m, a, b, c in T.round_times))
         for rb in srs.resident.values():
