@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/hekaton.h"
@@ -158,6 +159,12 @@ struct hk_ctx {
     hk_timings last;
     uint32_t max_lanes0 = 262144;   // level-0 accumulate lanes: 4 waves/SIMD x 1024 SIMDs x 64
     void* presize_kernel = nullptr; // k_scratch_presize<W> with the process's deepest frame (hk_core.hip)
+    // window tables of hk_fixed_base, kept per base: a trusted setup and the aggregator's SRS multiply the two generators
+    // again and again, and a table is a 248-step doubling chain (2 ms in G1, 5 - 6 ms in G2) in front of a 0.6 ms sweep.
+    // At most FB_CACHE_MAX entries, never evicted; freed with the context.
+    struct FbTable { int group; std::string base; void* table; bool ready; };
+    enum { FB_CACHE_MAX = 8 };
+    std::vector<FbTable> fb_cache;
 };
 
 struct hk_pk {

@@ -52,7 +52,7 @@ struct MsmRun {
     // fixed-base batch scalar multiplication (fixed_base.cuh); all pointers device.
     // table: 32*256 affine scratch, xy: n XYZZ scratch, pref: n field-element scratch
     static hk_status fixed_base(hipStream_t s, const Affine<F>* base, const void* scalars, int is_mont,
-                                u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out);
+                                u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out, bool build_table = true);
     static hk_status batch_affine(hipStream_t s, const XYZZ<F>* in, Affine<F>* out, F* pref, u32 n);
     // out[i] = scalars[i] * points[i] (pairing_ops.rs:32-39); xy / pref: n-element scratch
     // tab: 2^K x n XYZZ scratch (K = 2 in G1, 4 in G2) for the subset sums of the endomorphism images (nullptr: the plain

@@ -287,10 +287,10 @@ hk_status MsmRun<F>::lincomb(hipStream_t s, const Affine<F>* const* vecs, const 
 
 template <class F>
 hk_status MsmRun<F>::fixed_base(hipStream_t s, const Affine<F>* base, const void* scalars, int is_mont,
-                                u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out) {
+                                u32 n, Affine<F>* table, XYZZ<F>* xy, F* pref, Affine<F>* out, bool build_table) {
     typedef typename ScalarOf<F>::type Fr;
     if (n == 0) return HK_OK;
-    hipLaunchKernelGGL((k_fb_table<F>), dim3(FB_WINDOWS * 256 / 64), dim3(64), 0, s, base, table);
+    if (build_table) hipLaunchKernelGGL((k_fb_table<F>), dim3(FB_WINDOWS * 256 / 64), dim3(64), 0, s, base, table);
     hipLaunchKernelGGL((k_fb_mul<Fr, F>), dim3((n + 63) / 64), dim3(64), 0, s, table, (const Fr*)scalars,
                        is_mont, n, xy);
     HK_HIP(hipGetLastError());

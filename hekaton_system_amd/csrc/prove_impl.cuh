@@ -697,9 +697,14 @@ hk_status Ops<C>::bases_upload(hk_ctx* ctx, int group, const void* bases, size_t
     b->plan = msm_make_plan((u32)n, C::FR_BITS, msm_pick_c_tables(n, C::FR_BITS), 1u, ctx->max_lanes0, C::Fr::Params::MOD, C::Fr::Params::N);
     auto build = [&](auto ftag) -> hk_status {
         typedef decltype(ftag) F;
-        // a short G2 set is never multiplied through its tables (msm_bases): the 15 x (16 doublings + one inversion) per
-        // base of their construction - 10 ms per set, most of `tipa.setup` - are skipped
-        b->has_tables = !(sizeof(F) > sizeof(Fq) && n <= 2048 && !getenv("HK_MSM_NO_SMALL"));
+        // a short set goes without shift tables (msm_bases then runs n element-wise endomorphism products + one sum): their
+        // construction is 15 x (16 doublings + one inversion) per base - 6 ms per G1 set, 10 ms per G2 set, most of
+        // `tipa.setup`, whose four sets are multiplied ONCE per aggregation - against 0.3 - 0.5 ms saved per G1 product
+        // (1.0 - 1.3 ms with tables, 1.4 - 1.8 ms without; G2 is quicker without).  HK_BASES_TABLES=1: tables for G1 sets of
+        // any length, for a caller that multiplies one set many times
+        const bool g2 = sizeof(F) > sizeof(Fq);
+        const bool short_set = g2 ? n <= 2048 : (n <= 8192 && !getenv("HK_BASES_TABLES"));
+        b->has_tables = !(short_set && !getenv("HK_MSM_NO_SMALL"));
         size_t bytes = (size_t)(b->has_tables ? b->plan.F : 1u) * n * sizeof(Affine<F>);
         if (hipMalloc(&b->tab, bytes) != hipSuccess) { (void)hipGetLastError(); return HK_ERR_NOMEM; }
         b->bytes = bytes;
@@ -794,18 +799,48 @@ hk_status Ops<C>::fixed_base(hk_ctx* ctx, int group, const void* base, const voi
         size_t need = al256(sizeof(Affine<F>)) + al256(n * sizeof(Fr)) + al256(sizeof(Affine<F>) * FB_WINDOWS * 256) +
                       al256(n * sizeof(XYZZ<F>)) + al256(n * sizeof(F)) + al256(n * sizeof(Affine<F>)) + 8192;
         HK_TRY(L->reserve(need));
+        // the base's window table: from the context's cache when this base has been multiplied before (host bases only: the
+        // key is the base's bytes), else built now - into a cache slot when one is free, into the lane's scratch otherwise
+        const size_t tbytes = sizeof(Affine<F>) * FB_WINDOWS * 256;
+        Affine<F>* table = nullptr;
+        bool build = true;
+        int slot = -1;
+        if (!is_device_ptr(base) && !getenv("HK_FB_NO_CACHE")) {
+            std::string key((const char*)base, sizeof(Affine<F>));
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            for (auto& e : ctx->fb_cache)
+                if (e.group == group && e.base == key) {
+                    if (e.ready) { table = (Affine<F>*)e.table; build = false; }
+                    slot = -2;                                   // present (ready, or being built by another call)
+                    break;
+                }
+            if (slot == -1 && ctx->fb_cache.size() < (size_t)hk_ctx::FB_CACHE_MAX) {
+                void* t = nullptr;
+                if (hipMalloc(&t, tbytes) == hipSuccess) {
+                    ctx->fb_cache.push_back({group, key, t, false});
+                    slot = (int)ctx->fb_cache.size() - 1;
+                    table = (Affine<F>*)t;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+        }
         const void *bd, *sd;
         HK_TRY(to_device(L, base, sizeof(Affine<F>), &bd));
         HK_TRY(to_device(L, scalars, n * sizeof(Fr), &sd));
-        Affine<F>* table = L->alloc_n<Affine<F>>(FB_WINDOWS * 256);
+        if (!table) table = L->alloc_n<Affine<F>>(FB_WINDOWS * 256);
         XYZZ<F>* xy = L->alloc_n<XYZZ<F>>(n);
         F* pref = L->alloc_n<F>(n);
         bool out_dev = is_device_ptr(out);
         Affine<F>* od = out_dev ? (Affine<F>*)out : L->alloc_n<Affine<F>>(n);
         if (!table || !xy || !pref || !od) return HK_ERR_NOMEM;
-        HK_TRY(MsmRun<F>::fixed_base(L->stream, (const Affine<F>*)bd, sd, mont, (u32)n, table, xy, pref, od));
+        HK_TRY(MsmRun<F>::fixed_base(L->stream, (const Affine<F>*)bd, sd, mont, (u32)n, table, xy, pref, od, build));
         if (!out_dev) HK_HIP(hipMemcpyAsync(out, od, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, L->stream));
         HK_HIP(hipStreamSynchronize(L->stream));
+        if (slot >= 0) {                                         // the table is complete: later calls may read it
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->fb_cache[slot].ready = true;
+        }
         return HK_OK;
     };
     return group == 1 ? run(Fq()) : run(Fq2());
@@ -1335,6 +1370,9 @@ hk_status Ops<C>::field_convert(hk_ctx* ctx, int which, const void* in, void* ou
 
 template <class C>
 void Ops<C>::ctx_release(hk_ctx* ctx) {
+    for (auto& e : ctx->fb_cache)
+        if (e.table) (void)hipFree(e.table);
+    ctx->fb_cache.clear();
     if (!ctx->ntt) return;
     NttTables* T = ctx->ntt;
     for (void* p : {T->tw_fwd, T->tw_inv, T->pw_g, T->pw_ginv})

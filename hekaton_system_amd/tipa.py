@@ -53,17 +53,20 @@ def setup(ctx, curve, n, alpha, beta):
     p = CURVE_PARAMS[curve]
     fc = FrCodec(curve)
     r = p["r"]
-    pa, pb = [1] * (2 * n), [1] * (2 * n)
+    pa, pb = [fc.R % r] * (2 * n), [fc.R % r] * (2 * n)              # R * alpha^i: Montgomery values as they come
     for i in range(1, 2 * n):
         pa[i] = pa[i - 1] * alpha % r
         pb[i] = pb[i - 1] * beta % r
     G1, G2 = fc.g1(p["g1"]), fc.g2(p["g2"])
-    # four independent fixed-base sweeps, then four independent table builds: issued together (one lane each)
+    # two fixed-base sweeps (one per generator: its window table is built once, or comes from the context's cache), then
+    # four uploads: issued together (one lane each)
     with ThreadPoolExecutor(max_workers=4) as pool:
-        fs = [pool.submit(ctx.fixed_base, g, base, fc.enc(sc)) for g, base, sc in
-              ((1, G1, pa), (1, G1, pb), (2, G2, pa[:n]), (2, G2, pb[:n]))]
-        g_a, g_b, h_a, h_b = (np.asarray(f.result()) for f in fs)
-        g1b = ctx.g1_bytes
+        f1 = pool.submit(ctx.fixed_base, 1, G1, fc.enc_canon(pa + pb))
+        f2 = pool.submit(ctx.fixed_base, 2, G2, fc.enc_canon(pa[:n] + pb[:n]))
+        g1b, g2b = ctx.g1_bytes, ctx.g2_bytes
+        g_ab, h_ab = np.asarray(f1.result()), np.asarray(f2.result())
+        g_a, g_b = g_ab[:2 * n * g1b], g_ab[2 * n * g1b:]
+        h_a, h_b = h_ab[:n * g2b], h_ab[n * g2b:]
         ck = IPCommKey(v1=h_a, v2=h_b, w1=g_a[n * g1b:].copy(), w2=g_b[n * g1b:].copy(), n=n)
         srs = Srs(n, g_a, g_b, h_a, h_b, ck)
         ups = [pool.submit(ctx.bases_upload, g, v) for g, v in ((1, g_a), (1, g_b), (2, h_a), (2, h_b))]

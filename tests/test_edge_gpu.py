@@ -155,6 +155,44 @@ def test_scalar_pairing_like_reference(group, ctx_bn254):
 
 
 @pytest.mark.parametrize("group", [1, 2])
+def test_fixed_base_table_cache(group):
+    """hk_fixed_base keeps the window table of a base it has multiplied before (per context, at most 8 bases): the first
+    call (table built into a cache slot), the second (cache hit), a call with the cache switched off and the oracle agree;
+    twelve distinct bases - more than the cache holds - each against the oracle; the infinity base."""
+    import os
+    cp = BN254
+    cd = Codec(cp)
+    G = curve.G1(cp) if group == 1 else curve.G2(cp)
+    enc = cd.g1_vec if group == 1 else cd.g2_vec
+    dec = cd.g1_from if group == 1 else cd.g2_from
+    pb = cd.g1_bytes if group == 1 else cd.g2_bytes
+    rnd = random.Random(70 + group)
+    ctx = capi.Context("bn254", 0)
+    try:
+        ks = [0, 1, cp.r - 1] + [rnd.randrange(cp.r) for _ in range(30)]
+        sc = cd.fr_vec_mont(ks)
+        base = G.mul(G.gen, 12345)
+        first = ctx.fixed_base(group, enc([base]), sc).copy()
+        second = ctx.fixed_base(group, enc([base]), sc).copy()
+        os.environ["HK_FB_NO_CACHE"] = "1"
+        try:
+            plain = ctx.fixed_base(group, enc([base]), sc).copy()
+        finally:
+            del os.environ["HK_FB_NO_CACHE"]
+        assert np.array_equal(first, second) and np.array_equal(first, plain)
+        assert [dec(first[i * pb:(i + 1) * pb]) for i in range(len(ks))] == [G.mul(base, k) for k in ks]
+        for j in range(12):
+            bj = G.mul(G.gen, 1000 + j)
+            for _ in range(2):                                        # miss (or private build), then hit when cached
+                out = ctx.fixed_base(group, enc([bj]), cd.fr_vec_mont([j + 2, cp.r - 1 - j]))
+                assert [dec(out[:pb]), dec(out[pb:])] == [G.mul(bj, j + 2), G.mul(bj, cp.r - 1 - j)], j
+        out = ctx.fixed_base(group, enc([None]), cd.fr_vec_mont([5, 7]))
+        assert dec(out[:pb]) is None and dec(out[pb:]) is None
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("group", [1, 2])
 def test_resident_bases_msm_matches_plain_msm_and_oracle(group, ctx_bn254):
     """hk_bases_upload / hk_msm_bases (the aggregator's static-SRS MSMs, kzg.rs:151-152): same group element as the
     one-off hk_msm over the same bases and as the oracle's Pippenger; ark length semantics."""
@@ -167,7 +205,7 @@ def test_resident_bases_msm_matches_plain_msm_and_oracle(group, ctx_bn254):
     co = COracle("bn254")
     msm = ctx_bn254.msm_g1 if group == 1 else ctx_bn254.msm_g2
     pb = ctx_bn254.g1_bytes if group == 1 else ctx_bn254.g2_bytes
-    for n in (1, 2, 64, 1000, 5000):
+    for n in (1, 2, 64, 1000, 5000) + ((9000,) if group == 1 else ()):      # G1: shift tables from 8 193 bases on
         bases = ctx_bn254.fixed_base(group, gen, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)]))
         if n > 2:
             bases[pb:2 * pb] = 0                                    # an infinity base in the set
