@@ -38,7 +38,8 @@ def main():
     # ---- pairings: hk_multi_pairing (one product) and hk_pairing_products (the 4 x 4 cross terms, aggregation.rs:255-263)
     print("%-8s %8s %14s %16s %14s %18s" % ("pairing", "n", "1 product ms", "16 products ms", "cpu 1 prod ms", "cpu 16 prods ms"))
     gen1, gen2 = fc.g1(p["g1"]), fc.g2(p["g2"])
-    for n in (64, 256, 1024, 4096):
+    only_front = bool(os.environ.get("HK_AGG_FRONT_TRACE"))
+    for n in () if only_front else (64, 256, 1024, 4096):
         v1 = [ctx.fixed_base(1, gen1, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])) for _ in range(4)]
         v2 = [ctx.fixed_base(2, gen2, fc.enc([rnd.randrange(1, p["r"]) for _ in range(n)])) for _ in range(4)]
         d1 = [capi.DeviceBuffer.from_host(ctx, v) for v in v1]
@@ -73,7 +74,7 @@ def main():
     # ---- TIPP prove / verify (tipa.py): the whole GIPA recursion + KZG openings on random vectors
     from hekaton_system_amd import aggregation as agg, tipa
     print("%-8s %8s %14s %14s %14s" % ("tipp", "n", "setup ms", "prove ms", "verify ms"))
-    for n in (64, 256, 1024):
+    for n in () if only_front else (64, 256, 1024):
         t0 = time.time()
         srs = tipa.setup(ctx, curve, n, rnd.randrange(2, p["r"]), rnd.randrange(2, p["r"]))
         t_setup = time.time() - t0
@@ -107,7 +108,7 @@ def main():
     from hekaton_system_amd.merlin import Transcript as Merlin
     from hekaton_system_amd.workload import make_config, representative_subcircuit, unique_subcircuits
     print("%-8s %8s %14s %14s %12s %12s %12s %12s" % ("job", "n", "agg key ms", "super com ms", "front ms", "prove ms", "verify ms", "total ms"))
-    for n in (64, 1024):
+    for n in ((int(os.environ["HK_AGG_FRONT_TRACE"]),) if os.environ.get("HK_AGG_FRONT_TRACE") else (64, 1024)):
         keys = {}
         for rep in unique_subcircuits("big-merkle", n):
             circ = make_config(curve, "tiny", rep)
@@ -132,6 +133,10 @@ def main():
         T = tipa.Tipp(ctx, curve)
         vk = tipa.verifier_key(ctx, curve, srs)
         apk.agg_subcircuit_proofs(Merlin(b"bench"), super_com, proofs, pub, srs, tipp=T)          # warm
+        if os.environ.get("HK_AGG_FRONT_TRACE") == str(n):    # under `rocprofv3 --kernel-trace`: the front half alone after a
+            time.sleep(0.3)                                   # pause (tools/tipp_timeline.py show <csv> prints what follows it)
+            apk.agg_front(super_com, proofs, pub, pt=Merlin(b"bench"))
+            return
         if os.environ.get("HK_AGG_CPROFILE"):                 # where the HOST time of the front half and the verifier goes
             import cProfile
             import pstats
