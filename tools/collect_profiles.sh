@@ -38,6 +38,11 @@ for n in 64 1024; do
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/tipp_tl_$n -o run -- python3 tools/tipp_timeline.py run bn254 $n > $O/tipp_tl_$n.txt 2>&1 \
     && python3 tools/tipp_timeline.py show $(find $O/tipp_tl_$n -name "run_kernel_trace.csv") > $O/tipp_timeline_bn254_$n.txt || echo "tipp timeline $n failed"
 done
+echo "== kernel timelines of TIPA setup and of the aggregator's front half (1024 proofs)"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/setup_tl -o run -- python3 tools/tipp_timeline.py setup bn254 1024 > $O/setup_tl.txt 2>&1 \
+  && python3 tools/tipp_timeline.py show $(find $O/setup_tl -name "run_kernel_trace.csv") > $O/setup_timeline_bn254_1024.txt || echo "setup timeline failed"
+HK_AGG_FRONT_TRACE=1024 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/front_tl -o run -- python3 tools/agg_ops_bench.py bn254 > $O/front_tl.txt 2>&1 \
+  && python3 tools/tipp_timeline.py show $(find $O/front_tl -name "run_kernel_trace.csv") > $O/front_timeline_bn254_1024.txt || echo "front timeline failed"
 fi
 find $O -name "*.csv" | head -30
 echo done

@@ -11,6 +11,8 @@ cp $O/bench_under_rocprof_default.json $P/${R}_bench_under_rocprof_default.json
 cp $O/stats_serial/run_kernel_stats.csv $P/${R}_kernel_stats_serial_streams.csv
 cp $O/bench_under_rocprof_serial.json $P/${R}_bench_under_rocprof_serial_streams.json
 for n in 64 1024; do [ -s $O/tipp_timeline_bn254_$n.txt ] && cp $O/tipp_timeline_bn254_$n.txt $P/${R}_tipp_prove_timeline_bn254_$n.txt; done
+[ -s $O/setup_timeline_bn254_1024.txt ] && cp $O/setup_timeline_bn254_1024.txt $P/${R}_tipa_setup_timeline_bn254_1024.txt
+[ -s $O/front_timeline_bn254_1024.txt ] && cp $O/front_timeline_bn254_1024.txt $P/${R}_agg_front_timeline_bn254_1024.txt
 for a in bn254 bls12_381; do [ -s $O/agg_ops_$a.txt ] && cp $O/agg_ops_$a.txt $P/${R}_agg_ops_$a.txt; done
 for c in big-merkle-512x64 vm-1024x1024 vkd-256 big-merkle-4x1 big-merkle-sha-64x32 big-merkle-sha-64x32_witness_gen; do
   [ -s $O/bench_$c.json ] && cp $O/bench_$c.json $P/${R}_bench_$c.json
