@@ -346,30 +346,35 @@ class Job:
                          for c in self.classes.values()]
 
     def _finish_witnesses(self):
-        """After the first round: wait for the programs, then per class the ~50 full-width values the host computes
-        (portal entries, running evaluations, address-step flags: hk_assignment_scatter) and the membership block
-        (execution-tree leaf hash + path, subcircuit_circuit.rs:233-252: hk_poseidon_path), classes side by side.
-        Returns the seconds this added to the step (the programs' own time is hidden behind round 1 unless they are
-        still running here)."""
+        """After the first round: per class the ~50 full-width values the host computes (portal entries, running
+        evaluations, address-step flags: hk_assignment_scatter) and the membership block (execution-tree leaf hash + path,
+        subcircuit_circuit.rs:233-252: hk_poseidon_path), classes side by side and beside whatever is left of the programs.
+        Returns the seconds this added to the step."""
         from hekaton_system_amd.sha_circuit import full_values, poseidon_inputs
         t0 = time.time()
         trace = bool(os.environ.get("HK_WG_TRACE"))
-        for f in self._wg_futs:
-            f.result()
+        # the host's share first (the programs may still be running on the GPU): per class the full-width values and the
+        # membership inputs, both functions of the round's challenges
+        for c in self.classes.values():
+            c["_wg_full"], c["_wg_pos"] = full_values(c["circ"], c["wg_ws"]), poseidon_inputs(c["circ"], c["wg_ws"])
         t1 = time.time()
 
         def full(c):
-            cols, vals = full_values(c["circ"], c["wg_ws"])
+            cols, vals = c["_wg_full"]
             c["wprog"].scatter(cols, vals, c["zbig"])
 
         def membership(c):
             circ = c["circ"]
-            leaves, sibs, idx = poseidon_inputs(circ, c["wg_ws"])
+            leaves, sibs, idx = c["_wg_pos"]
             self.ctx.poseidon_path(self.poseidon_params, leaves, sibs, idx, circ.n_v, circ.pos_col0, c["zbig"])
 
+        # ... and straight to the GPU, beside the programs: the expansion of a program's bits writes the bit-valued columns
+        # only (k_witness_expand leaves the full-width ones alone), these calls the full-width ones only
         list(self.pool.map(lambda job: job[0](job[1]), [(f, c) for f in (membership, full) for c in self.classes.values()]))
+        for f in self._wg_futs:
+            f.result()
         if trace:
-            log("witness gen: programs started %.1f ms before the gather ended, waited %.1f ms for them, full values + membership %.1f ms"
+            log("witness gen: programs started %.1f ms before the gather ended, host values %.1f ms, scatter + membership + programs' rest %.1f ms"
                 % ((t0 - self._wg_t0) * 1e3, (t1 - t0) * 1e3, (time.time() - t1) * 1e3))
         return time.time() - t0
 

@@ -1079,6 +1079,13 @@ hk_status Ops<C>::wprog_upload(hk_ctx* ctx, const uint32_t* ops, size_t n_ops, c
                 ok = (size_t)o[1] + 4 <= n_refs;
                 for (uint32_t j = 0; ok && j < 4; j++) ok = ref_ok(refs[o[1] + j]);
                 break;
+            case WOP_SHA_ROUND: case WOP_SHA_SCHED: {
+                const uint32_t nr = o[0] == WOP_SHA_ROUND ? 9u : 4u;
+                ok = (size_t)o[1] + nr <= n_refs;
+                for (uint32_t j = 0; ok && j < nr; j++) ok = ref_ok(refs[o[1] + j]);
+                vid += (o[0] == WOP_SHA_ROUND ? WOP_ROUND_VALUES : WOP_SCHED_VALUES) - 1;
+                break;
+            }
             default: ok = false;
         }
         if (!ok) return HK_ERR_ARG;

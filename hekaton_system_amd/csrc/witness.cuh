@@ -16,7 +16,11 @@
 
 namespace hk {
 
-enum { WOP_INPUT = 0, WOP_CONST, WOP_XOR, WOP_CH, WOP_AND, WOP_MAJ, WOP_ADD, WOP_PACK4 };
+enum { WOP_INPUT = 0, WOP_CONST, WOP_XOR, WOP_CH, WOP_AND, WOP_MAJ, WOP_ADD, WOP_PACK4,
+       // one SHA-256 round / one message-schedule step as ONE entry producing the 11 / 6 values its gadget entries would, in
+       // their order (sha_circuit.py OP_SHA_ROUND / OP_SHA_SCHED): the chain pays decode + ring round trips once per round
+       WOP_SHA_ROUND, WOP_SHA_SCHED };
+constexpr unsigned WOP_ROUND_VALUES = 11, WOP_SCHED_VALUES = 6;
 
 #if defined(__HIPCC__)
 
@@ -83,6 +87,31 @@ k_word_program(const u32* __restrict__ ops, u32 n_ops, const u32* __restrict__ r
                 u64 tot = imm;
                 for (u32 j = 0; j < o.z; j++) tot += wp_ref(values, ring, refs[o.y + j], vid, batch, lane);
                 put((u32)tot);
+                r = (u32)(tot >> 32);
+                break;
+            }
+            case WOP_SHA_ROUND: {
+                const u32 v0 = vid;                               // operands are older than every value of this entry
+                u32 in[9];
+                for (u32 j = 0; j < 9; j++) in[j] = wp_ref(values, ring, refs[o.y + j], v0, batch, lane);
+                const u32 a = in[0], b = in[1], c = in[2], d = in[3], e = in[4], f = in[5], g = in[6], h = in[7], w = in[8];
+                auto rotr = [](u32 x, u32 k) { return (x >> k) | (x << (32u - k)); };
+                u32 x = rotr(e, 6) ^ rotr(e, 11), s1 = x ^ rotr(e, 25), ch = (e & f) ^ (~e & g);
+                u32 y = rotr(a, 2) ^ rotr(a, 13), s0 = y ^ rotr(a, 22), ab = a & b, mj = (a & b) ^ (a & c) ^ (b & c);
+                u64 te = (u64)imm + d + h + s1 + ch + w, ta = (u64)imm + h + s1 + ch + w + s0 + mj;
+                put(x); put(s1); put(ch); put(y); put(s0); put(ab); put(mj);
+                put((u32)te); put((u32)(te >> 32)); put((u32)ta);
+                r = (u32)(ta >> 32);
+                break;
+            }
+            case WOP_SHA_SCHED: {
+                const u32 v0 = vid;
+                u32 w15 = wp_ref(values, ring, refs[o.y], v0, batch, lane), w2 = wp_ref(values, ring, refs[o.y + 1], v0, batch, lane);
+                u32 w7 = wp_ref(values, ring, refs[o.y + 2], v0, batch, lane), w16 = wp_ref(values, ring, refs[o.y + 3], v0, batch, lane);
+                auto rotr = [](u32 x, u32 k) { return (x >> k) | (x << (32u - k)); };
+                u32 x0 = rotr(w15, 7) ^ rotr(w15, 18), s0 = x0 ^ (w15 >> 3), x1 = rotr(w2, 17) ^ rotr(w2, 19), s1 = x1 ^ (w2 >> 10);
+                u64 tot = (u64)s1 + w7 + s0 + w16;
+                put(x0); put(s0); put(x1); put(s1); put((u32)tot);
                 r = (u32)(tot >> 32);
                 break;
             }

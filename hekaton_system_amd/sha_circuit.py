@@ -32,7 +32,9 @@ instead of 32 bytes per variable; `hk`'s Montgomery expansion is a table lookup 
 SHA-256 gadget cost here: 26.8 k constraints per compression (XOR 1 constraint / bit, Ch 1, Maj 2, modular additions
 1 + booleanity of result and carry bits).
 """
+import contextlib
 import hashlib
+import os
 
 import numpy as np
 
@@ -78,6 +80,14 @@ def _shr(w, k):
 
 # word-program opcodes (interpreted by k_word_program on the GPU and by `run_word_program` on the host)
 OP_INPUT, OP_CONST, OP_XOR, OP_CH, OP_AND, OP_MAJ, OP_ADD, OP_PACK4 = range(8)
+# Macro entries: one SHA-256 round / one message-schedule step as ONE program entry that produces the same values, in the
+# same order, as the entries of its gadgets would (the interpreter pays its per-entry cost - decode, operand round trips
+# through the lane's ring - once per round instead of nine times):
+#   OP_SHA_ROUND  refs[a .. a+9) = a, b, c, d, e, f, g, h, w; imm = K[t]; 11 values: r6^r11 (e), S1, ch, r2^r13 (a), S0,
+#                 a & b, maj, (d + h + S1 + ch + w + K) low / carry, (h + S1 + ch + w + S0 + maj + K) low / carry
+#   OP_SHA_SCHED  refs[a .. a+4) = w[t-15], w[t-2], w[t-7], w[t-16]; 6 values: r7^r18, s0, r17^r19, s1, the sum's low / carry
+OP_SHA_ROUND, OP_SHA_SCHED = 8, 9
+OP_VALUES = {OP_ADD: 2, OP_SHA_ROUND: 11, OP_SHA_SCHED: 6}          # values per entry (1 otherwise)
 
 
 class Tape:
@@ -87,6 +97,7 @@ class Tape:
         self.n_inst = n_inst
         self.batch = batch
         self.build = batch == 0
+        self.macro_ops = not os.environ.get("HK_WPROG_NO_MACRO")       # one entry per SHA-256 round / schedule step
         self.n_wit = 0
         self.n_rows = 0
         self.trip = {m: [] for m in "ABC"}      # lists of (rows, cols, coefs) int64 arrays
@@ -100,12 +111,28 @@ class Tape:
         self.n_values = 0
         self.n_inputs = 0
         self.alloc_map = []                     # (first column, bit positions, value id)
+        self._in_macro = False
 
     def _value(self, op, a=0, b=0, c=0, imm=0, count=1):
         vid = self.n_values
-        self.prog.append((op, a, b, c, imm))
+        if not self._in_macro:
+            self.prog.append((op, a, b, c, imm))
         self.n_values += count
         return vid
+
+    @contextlib.contextmanager
+    def _macro(self, op, words, imm=0):
+        """The gadget calls inside the block allocate their values and rows as always, but the program gets ONE entry."""
+        assert not self._in_macro
+        first_ref, start = len(self.refs), self.n_values
+        self.refs += [w.ref() for w in words]
+        self._in_macro = True
+        try:
+            yield
+        finally:
+            self._in_macro = False
+        assert self.n_values - start == OP_VALUES[op]
+        self.prog.append((op, first_ref, len(words), 0, imm))
 
     def input_value(self):
         """The next 32-bit input of the subcircuit (a leaf word, a byte of a child hash) as a program value."""
@@ -253,10 +280,13 @@ class Tape:
     def sha256_compress(self, state, block):
         """state: 8 Words or ints (the IV); block: 16 Words (big-endian message words).  Returns 8 Words."""
         w = list(block)
+        macro = self.macro_ops
+        nothing = contextlib.nullcontext()
         for t in range(16, 64):
-            s0 = self.xor3(_rotr(w[t - 15], 7), _rotr(w[t - 15], 18), _shr(w[t - 15], 3))
-            s1 = self.xor3(_rotr(w[t - 2], 17), _rotr(w[t - 2], 19), _shr(w[t - 2], 10))
-            w.append(self.add([s1, w[t - 7], s0, w[t - 16]]))
+            with (self._macro(OP_SHA_SCHED, [w[t - 15], w[t - 2], w[t - 7], w[t - 16]]) if macro else nothing):
+                s0 = self.xor3(_rotr(w[t - 15], 7), _rotr(w[t - 15], 18), _shr(w[t - 15], 3))
+                s1 = self.xor3(_rotr(w[t - 2], 17), _rotr(w[t - 2], 19), _shr(w[t - 2], 10))
+                w.append(self.add([s1, w[t - 7], s0, w[t - 16]]))
         first = isinstance(state[0], int)
         if first:                          # IV: witnessed constant words (booleanity rows pin nothing; equality rows do)
             st = [self.const_word(v) for v in state]
@@ -264,12 +294,13 @@ class Tape:
             st = list(state)
         a, b, c, d, e, f, g, h = st
         for t in range(64):
-            S1 = self.xor3(_rotr(e, 6), _rotr(e, 11), _rotr(e, 25))
-            chv = self.ch(e, f, g)
-            S0 = self.xor3(_rotr(a, 2), _rotr(a, 13), _rotr(a, 22))
-            mj = self.maj(a, b, c)
-            new_e = self.add([d, h, S1, chv, w[t]], K256[t])
-            new_a = self.add([h, S1, chv, w[t], S0, mj], K256[t])
+            with (self._macro(OP_SHA_ROUND, [a, b, c, d, e, f, g, h, w[t]], K256[t]) if macro else nothing):
+                S1 = self.xor3(_rotr(e, 6), _rotr(e, 11), _rotr(e, 25))
+                chv = self.ch(e, f, g)
+                S0 = self.xor3(_rotr(a, 2), _rotr(a, 13), _rotr(a, 22))
+                mj = self.maj(a, b, c)
+                new_e = self.add([d, h, S1, chv, w[t]], K256[t])
+                new_a = self.add([h, S1, chv, w[t], S0, mj], K256[t])
             a, b, c, d, e, f, g, h = new_a, a, b, c, new_e, e, f, g
         return [self.add([x, y]) for x, y in zip(st, [a, b, c, d, e, f, g, h])]
 
@@ -978,6 +1009,7 @@ def run_word_program(ops, refs, n_values, inputs):
     B = inputs.shape[0]
     values = np.zeros((n_values, B), np.uint32)
     vid = 0
+    rot = lambda v, k: (v >> np.uint32(k)) | (v << np.uint32(32 - k))
     for op, a, b, c, imm in ops[:, :5].tolist():
         if op == OP_INPUT:
             values[vid] = inputs[:, imm]
@@ -1003,6 +1035,31 @@ def run_word_program(ops, refs, n_values, inputs):
         elif op == OP_PACK4:
             p = [values[int(refs[a + k]) & 0xfffff] for k in range(4)]
             values[vid] = (p[0] << np.uint32(24)) | (p[1] << np.uint32(16)) | (p[2] << np.uint32(8)) | p[3] | np.uint32(imm)
+        elif op == OP_SHA_ROUND:
+            ra, rb, rc, rd, re, rf, rg, rh, rw = (_ref_val(values, int(refs[a + k])) for k in range(9))
+            x = rot(re, 6) ^ rot(re, 11)
+            s1 = x ^ rot(re, 25)
+            chv = (re & rf) ^ (~re & rg)
+            y = rot(ra, 2) ^ rot(ra, 13)
+            s0 = y ^ rot(ra, 22)
+            t_ab = ra & rb
+            mj = (ra & rb) ^ (ra & rc) ^ (rb & rc)
+            u64 = lambda *ws: sum((w_.astype(np.uint64) for w_ in ws), np.full(B, imm, np.uint64))
+            te, ta = u64(rd, rh, s1, chv, rw), u64(rh, s1, chv, rw, s0, mj)
+            lo, hi = (lambda v: (v & np.uint64(0xffffffff)).astype(np.uint32)), (lambda v: (v >> np.uint64(32)).astype(np.uint32))
+            for j, v in enumerate((x, s1, chv, y, s0, t_ab, mj, lo(te), hi(te), lo(ta), hi(ta))):
+                values[vid + j] = v
+            vid += 10
+        elif op == OP_SHA_SCHED:
+            w15, w2, w7, w16 = (_ref_val(values, int(refs[a + k])) for k in range(4))
+            x0 = rot(w15, 7) ^ rot(w15, 18)
+            s0 = x0 ^ (w15 >> np.uint32(3))
+            x1 = rot(w2, 17) ^ rot(w2, 19)
+            s1 = x1 ^ (w2 >> np.uint32(10))
+            tot = s1.astype(np.uint64) + w7.astype(np.uint64) + s0.astype(np.uint64) + w16.astype(np.uint64)
+            for j, v in enumerate((x0, s0, x1, s1, (tot & np.uint64(0xffffffff)).astype(np.uint32), (tot >> np.uint64(32)).astype(np.uint32))):
+                values[vid + j] = v
+            vid += 5
         vid += 1
     assert vid == n_values
     return values

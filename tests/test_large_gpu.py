@@ -261,8 +261,8 @@ def test_assignment_materialised_on_the_device_equals_the_host_bytes(ctx_bn254):
         ctx_bn254.assignment_from_bits(np.zeros(circ.n_v, np.uint8), bad_cols, FrCodec("bn254").enc([1]))
 
 
-@pytest.mark.parametrize("kind", ["leaf", "parent"])
-def test_witness_generated_on_the_device_equals_the_host_trace(kind, ctx_bn254):
+@pytest.mark.parametrize("kind,macro", [("leaf", True), ("parent", True), ("parent", False)])
+def test_witness_generated_on_the_device_equals_the_host_trace(kind, macro, ctx_bn254, monkeypatch):
     """hk_wprog_upload / hk_wprog_run + hk_poseidon_path (csrc/witness.cuh): the class's word program interpreted on the
     GPU from the subcircuits' inputs, and the Poseidon membership block computed on the GPU from the execution leaf and
     its path, give bit for bit the assignments the host trace emits (themselves checked against hashlib, poseidon.py and
@@ -273,9 +273,12 @@ def test_witness_generated_on_the_device_equals_the_host_trace(kind, ctx_bn254):
                                                 program_inputs)
     cname = "bn254"
     fc = FrCodec(cname)
+    if not macro:               # one program entry per gadget (XOR, Ch, Maj, additions) instead of one per round / schedule step
+        monkeypatch.setenv("HK_WPROG_NO_MACRO", "1")
     circ = ShaMerkleSubcircuit(cname, kind, ns=2, n_portals=4, depth=5)
     ws = [example_witness(circ, seed=s, entry_chal=31, tr_chal=41) for s in range(5)]
     ops, refs, vmap = circ.tape.word_program(circ.n_v)
+    assert bool(np.any(ops[:, 0] >= 8)) == macro
     wp = ctx_bn254.wprog_upload(ops, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
     cols, vals = full_values(circ, ws)
     zdev = wp.run(program_inputs(circ, ws), cols, vals)
@@ -291,10 +294,26 @@ def test_witness_generated_on_the_device_equals_the_host_trace(kind, ctx_bn254):
     ctx_bn254.poseidon_path(device_params(cname, fc), leaves, sibs, idx, circ.n_v, circ.pos_col0, z2)
     assert np.array_equal(z2.to_host().reshape(len(ws), -1), want)
     z2.free()
+    if not macro:
+        bad = ops.copy()
+        bad[int(np.nonzero(bad[:, 0] == 2)[0][0]), 1] = circ.tape.n_values - 1
+        with pytest.raises(capi.HekatonError) as e:
+            ctx_bn254.wprog_upload(bad, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
+        assert e.value.status == capi.HK_ERR_ARG
+        zdev.free()
+        return
     # a malformed program (operand reference beyond the values defined so far) is refused, not interpreted
+    from hekaton_system_amd.sha_circuit import OP_SHA_ROUND, OP_SHA_SCHED
+    for opcode, n_operands in ((OP_SHA_ROUND, 9), (OP_SHA_SCHED, 4)):
+        k = int(np.nonzero(ops[:, 0] == opcode)[0][0])                  # the first round / schedule step of the program
+        for j in (0, n_operands - 1):
+            bad_refs = refs.copy()
+            bad_refs[ops[k, 1] + j] = circ.tape.n_values - 1
+            with pytest.raises(capi.HekatonError) as e:
+                ctx_bn254.wprog_upload(ops, bad_refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
+            assert e.value.status == capi.HK_ERR_ARG
     bad = ops.copy()
-    k = int(np.nonzero(bad[:, 0] == 2)[0][0])
-    bad[k, 1] = circ.tape.n_values - 1
+    bad[int(np.nonzero(ops[:, 0] == OP_SHA_ROUND)[0][-1]), 1] = len(refs) - 3   # operand table runs past the reference array
     with pytest.raises(capi.HekatonError) as e:
         ctx_bn254.wprog_upload(bad, refs, vmap, circ.tape.n_values, circ.tape.n_inputs)
     assert e.value.status == capi.HK_ERR_ARG
