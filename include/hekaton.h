@@ -272,6 +272,11 @@ hk_status hk_assignment_from_bits(hk_ctx* ctx, const void* bits, size_t n_v, con
  * distributed-prover/src/tree_hash_circuit.rs:313-398) for a re-implemented gadget set (csrc/witness.cuh).
  *   ops [h]: n_ops x 8 u32 (opcode, a, b, c, imm, 0, 0, 0): 0 INPUT imm | 1 CONST imm | 2 XOR a b | 3 CH a b c | 4 AND a b |
  *            5 MAJ a b c | 6 ADD refs[a .. a+b) + imm -> TWO values (low word, carry) | 7 PACK4 refs[a .. a+4) | imm;
+ *            8 SHA_ROUND refs[a .. a+9) = (a b c d e f g h w), imm = K_t -> ELEVEN values, those of the round's gadget
+ *            entries in their order (rotr6^rotr11 of e, Sigma1, Ch, rotr2^rotr13 of a, Sigma0, a & b, Maj, low / carry of
+ *            d + h + Sigma1 + Ch + w + K, low / carry of h + Sigma1 + Ch + w + Sigma0 + Maj + K) | 9 SHA_SCHED
+ *            refs[a .. a+4) = (w[t-15] w[t-2] w[t-7] w[t-16]) -> SIX values (rotr7^rotr18, sigma0, rotr17^rotr19, sigma1,
+ *            low / carry of sigma1 + w[t-7] + sigma0 + w[t-16]);
  *            an operand = value id | rotate-right << 20 | shift-right << 25; every entry defines the next value id(s)
  *   map [h]: n_v u32, value id << 5 | bit position, or 0xffffffff for instance / full-width columns
  *   hk_wprog_run: inputs [h|d] batch x n_inputs u32; full_cols [h|d] n_full columns; full_vals_mont [h|d] batch x n_full Fr;
