@@ -353,24 +353,26 @@ class Job:
         from hekaton_system_amd.sha_circuit import full_values, poseidon_inputs
         t0 = time.time()
         trace = bool(os.environ.get("HK_WG_TRACE"))
-        # the host's share first (the programs may still be running on the GPU): per class the full-width values and the
-        # membership inputs, both functions of the round's challenges
-        for c in self.classes.values():
-            c["_wg_full"], c["_wg_pos"] = full_values(c["circ"], c["wg_ws"]), poseidon_inputs(c["circ"], c["wg_ws"])
-        t1 = time.time()
+        # the membership kernel is the longest piece (a chain of eight Poseidon permutations on one lane per subcircuit, 5 ms):
+        # its inputs first and straight to the GPU, beside the programs - the expansion of a program's bits writes the
+        # bit-valued columns only (k_witness_expand), these calls the full-width ones only -, then the host computes the
+        # full-width values while it runs, then the scatter
+        def membership(c):
+            circ = c["circ"]
+            leaves, sibs, idx = poseidon_inputs(circ, c["wg_ws"])
+            self.ctx.poseidon_path(self.poseidon_params, leaves, sibs, idx, circ.n_v, circ.pos_col0, c["zbig"])
 
         def full(c):
             cols, vals = c["_wg_full"]
             c["wprog"].scatter(cols, vals, c["zbig"])
 
-        def membership(c):
-            circ = c["circ"]
-            leaves, sibs, idx = c["_wg_pos"]
-            self.ctx.poseidon_path(self.poseidon_params, leaves, sibs, idx, circ.n_v, circ.pos_col0, c["zbig"])
-
-        # ... and straight to the GPU, beside the programs: the expansion of a program's bits writes the bit-valued columns
-        # only (k_witness_expand leaves the full-width ones alone), these calls the full-width ones only
-        list(self.pool.map(lambda job: job[0](job[1]), [(f, c) for f in (membership, full) for c in self.classes.values()]))
+        mem = [self.pool.submit(membership, c) for c in self.classes.values()]
+        for c in self.classes.values():
+            c["_wg_full"] = full_values(c["circ"], c["wg_ws"])
+        t1 = time.time()
+        list(self.pool.map(full, self.classes.values()))
+        for f in mem:
+            f.result()
         for f in self._wg_futs:
             f.result()
         if trace:
