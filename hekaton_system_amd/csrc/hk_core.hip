@@ -107,7 +107,7 @@ hk_status Lane::reserve(size_t bytes) {
     arena_off = 0;
     if (bytes <= arena_cap) return HK_OK;
     HK_HIP(hipStreamSynchronize(stream));
-    if (arena) HK_HIP(hipFree(arena));
+    if (arena) retired.push_back(arena);          // not hipFree here: it would wait for every other lane's kernels
     arena = nullptr;
     arena_cap = 0;
     size_t want = bytes + bytes / 8 + (1u << 20);
@@ -124,8 +124,11 @@ hk_status Lane::reserve(size_t bytes) {
 LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
     std::unique_lock<std::mutex> lk(ctx->mu);
     for (;;) {
+        // among the free lanes the one with the largest scratch arena: a lane that has to grow its arena frees the old one,
+        // and hipFree waits for the whole device - with calls of mixed sizes side by side (the aggregator: 6 ms pairing
+        // calls beside 1 ms folds) a big call on a small lane stalled everything for milliseconds
         for (Lane* l : ctx->lanes)
-            if (!l->busy) { lane = l; break; }
+            if (!l->busy && (!lane || l->arena_cap > lane->arena_cap)) lane = l;
         if (lane) break;
         if (ctx->lanes.size() < ctx->max_lanes) {
             Lane* l = new Lane();
@@ -190,6 +193,15 @@ LaneGuard::~LaneGuard() {
     lane->busy = false;
     ctx->last = lane->timings;
     tl_last_timings = lane->timings;
+    bool idle = true;
+    for (Lane* l : ctx->lanes) idle = idle && !l->busy;
+    if (idle)                                      // nothing of this context is on the GPU: outgrown arenas go now
+        for (Lane* l : ctx->lanes) {
+            if (l->retired.empty()) continue;
+            (void)hipSetDevice(ctx->device);
+            for (void* p : l->retired) (void)hipFree(p);
+            l->retired.clear();
+        }
     lk.unlock();
     ctx->cv.notify_one();
 }
@@ -279,6 +291,7 @@ void hk_ctx_destroy(hk_ctx* ctx) {
     if (ctx->ops && ctx->ops->ctx_release) ctx->ops->ctx_release(ctx);
     for (Lane* l : ctx->lanes) {
         if (l->arena) (void)hipFree(l->arena);
+        for (void* p : l->retired) (void)hipFree(p);
         if (l->pinned) (void)hipHostFree(l->pinned);
         for (auto& e : l->ev) (void)hipEventDestroy(e);
         for (auto& a : l->aux) if (a) (void)hipStreamDestroy(a);

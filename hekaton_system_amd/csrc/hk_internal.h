@@ -71,6 +71,7 @@ struct Lane {
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork/join side streams of hk_prove
     bool busy = false;
     hk_timings timings;
+    std::vector<void*> retired;   // outgrown arenas: freed when no call is in flight (hipFree waits for the whole device)
 
     hk_status reserve(size_t bytes);                 // ensure capacity (may sync + realloc), reset
     void* alloc(size_t bytes) {                      // bump allocation, 256-B aligned
