@@ -107,6 +107,20 @@ hk_status Lane::reserve(size_t bytes) {
     arena_off = 0;
     if (bytes <= arena_cap) return HK_OK;
     HK_HIP(hipStreamSynchronize(stream));
+    if (owner) {
+        // an idle lane of the context may hold an arena that is large enough (an earlier call of this size ran there):
+        // trade arenas with it - the smallest that fits - instead of allocating (a hipMalloc of tens of MB takes
+        // milliseconds, and which lane a call lands on is arbitrary).  An idle lane's stream has nothing in flight.
+        std::lock_guard<std::mutex> lk(owner->mu);
+        Lane* best = nullptr;
+        for (Lane* l : owner->lanes)
+            if (l != this && !l->busy && l->arena_cap >= bytes && (!best || l->arena_cap < best->arena_cap)) best = l;
+        if (best) {
+            std::swap(arena, best->arena);
+            std::swap(arena_cap, best->arena_cap);
+            return HK_OK;
+        }
+    }
     if (arena) retired.push_back(arena);          // not hipFree here: it would wait for every other lane's kernels
     arena = nullptr;
     arena_cap = 0;
@@ -182,7 +196,7 @@ LaneGuard::LaneGuard(hk_ctx* c) : ctx(c), lane(nullptr) {
         }
         ctx->cv.wait(lk);
     }
-    if (lane) lane->busy = true;
+    if (lane) { lane->busy = true; lane->owner = ctx; }
     lk.unlock();
     (void)hipSetDevice(ctx->device);
 }

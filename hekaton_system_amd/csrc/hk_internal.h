@@ -72,6 +72,7 @@ struct Lane {
     bool busy = false;
     hk_timings timings;
     std::vector<void*> retired;   // outgrown arenas: freed when no call is in flight (hipFree waits for the whole device)
+    hk_ctx* owner = nullptr;      // the context the lane belongs to (reserve() may trade arenas with an idle lane of it)
 
     hk_status reserve(size_t bytes);                 // ensure capacity (may sync + realloc), reset
     void* alloc(size_t bytes) {                      // bump allocation, 256-B aligned
