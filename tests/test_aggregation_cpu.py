@@ -49,6 +49,13 @@ def test_ipa_polynomial_and_division():
     fx = sum(c * pow(x, i, r) for i, c in enumerate(coeffs)) % r
     qx = sum(c * pow(x, i, r) for i, c in enumerate(q)) % r
     assert ((x - z) * qx + fz) % r == fx
+    # the Montgomery-scaled form the prover uses: R f(X), whose quotient by (X - z) is R q(X) - no product per coefficient
+    # when the quotient's Montgomery bytes are written out
+    from hekaton_system_amd.cp_groth16 import FrCodec
+    fc = FrCodec("bn254")
+    scaled = tipa.ipa_polynomial_coeffs(ch, shift, r, fc.R)
+    assert scaled == [c * fc.R % r for c in coeffs]
+    assert bytes(fc.enc_canon(tipa._divide_by_linear(scaled, z, r))) == bytes(fc.enc(q))
 
 
 def test_transcript_is_deterministic_and_order_sensitive():
