@@ -805,6 +805,16 @@ hk_status Ops<C>::fixed_base(hk_ctx* ctx, int group, const void* base, const voi
         Affine<F>* table = nullptr;
         bool build = true;
         int slot = -1;
+        struct SlotGuard {                                       // a call that fails after claiming a slot retires it: the
+            hk_ctx* c;                                           // entry never matches again (its base may claim another)
+            int* slot;
+            bool done;
+            ~SlotGuard() {
+                if (*slot < 0 || done) return;
+                std::lock_guard<std::mutex> lk(c->mu);
+                c->fb_cache[*slot].group = -1;
+            }
+        } claimed{ctx, &slot, false};
         if (!is_device_ptr(base) && !getenv("HK_FB_NO_CACHE")) {
             std::string key((const char*)base, sizeof(Affine<F>));
             std::lock_guard<std::mutex> lk(ctx->mu);
@@ -841,6 +851,7 @@ hk_status Ops<C>::fixed_base(hk_ctx* ctx, int group, const void* base, const voi
             std::lock_guard<std::mutex> lk(ctx->mu);
             ctx->fb_cache[slot].ready = true;
         }
+        claimed.done = true;
         return HK_OK;
     };
     return group == 1 ? run(Fq()) : run(Fq2());
