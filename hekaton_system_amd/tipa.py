@@ -23,6 +23,7 @@ GPU work per round: 10 multi-pairings of n/2 pairs (two hk_pairing_products call
 (hk_points_lincomb); at the end four MSMs over the resident SRS (hk_msm_bases).
 """
 import hashlib
+import os
 import time
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
@@ -130,6 +131,126 @@ def _divide_by_linear(coeffs, z, mod):
     return q                      # q[n-1] = 0: same length as the SRS slice, as kzg.rs:133-135 resizes it
 
 
+# vectors of the recursion, by their index in the arena: G1 vectors fold with the challenge c, G2 vectors with 1 / c
+_A, _B, _V1, _V2, _W1, _W2 = range(6)
+_G1_VECS, _G2_VECS = (_A, _W1, _W2), (_B, _V1, _V2)
+# a round's messages as inner products <X, Y> between a G1 vector X and a G2 vector Y: T over (a, v1) and (w1, b), U over
+# (a, v2) and (w2, b), Z over (a, b); the L message pairs X's right half with Y's left half, the R message the reverse
+_NAME_PAIRS = ((_A, _V1), (_W1, _B), (_A, _V2), (_W2, _B), (_A, _B))
+_MESSAGES = (("T", (0, 1)), ("U", (2, 3)), ("Z", (4,)))
+# quarter-by-quarter inner products E[i][j] = <X_i, Y_j> a pair of rounds needs (X = X_0 | X_1 | X_2 | X_3):
+#   round k      L: <X_R, Y_L> = E[2][0] E[3][1]                           R: <X_L, Y_R> = E[0][2] E[1][3]
+#   round k + 1  on X' = X_L + c X_R, Y' = Y_L + Y_R / c (bilinearity):
+#                L: <X'_R, Y'_L> = E[1][0] E[1][2]^(1/c) E[3][0]^c E[3][2]    R: <X'_L, Y'_R> = E[0][1] E[0][3]^(1/c) E[2][1]^c E[2][3]
+_QUARTERS = ((2, 0), (3, 1), (0, 2), (1, 3), (1, 0), (1, 2), (3, 0), (3, 2), (0, 1), (0, 3), (2, 1), (2, 3))
+_Q = {ij: t for t, ij in enumerate(_QUARTERS)}
+
+
+def _fold(ctx, go, win, pos, m, c, c_inv):
+    """The six vectors of size m at `pos` folded to size m / 2 right behind them; returns the new position."""
+    h, nxt = m // 2, pos + m
+    L = lambda k: win(k, pos, h)
+    R = lambda k: win(k, pos + h, h)
+    # the three G1 folds share c, the three G2 folds 1 / c: one batched call per group, issued together (the G2 fold is
+    # the longer one: it goes out from this thread, the G1 fold beside it from the pool)
+    g1_fold = go(ctx.points_fold_many, 1, [L(k) for k in _G1_VECS], [R(k) for k in _G1_VECS], c, h, [win(k, nxt, h) for k in _G1_VECS])
+    ctx.points_fold_many(2, [L(k) for k in _G2_VECS], [R(k) for k in _G2_VECS], c_inv, h, [win(k, nxt, h) for k in _G2_VECS])
+    g1_fold.result()
+    return nxt
+
+
+def _single_round(ctx, F, r, win, pos, m, tr, go, rounds, challenges, times):
+    h = m // 2
+    L = lambda k: win(k, pos, h)
+    R = lambda k: win(k, pos + h, h)
+    # all ten multi-pairings of the round in ONE batched call: ten (lhs, rhs) pairs out of 6 x 6, every G2 vector's Miller
+    # lines computed once
+    t0 = time.perf_counter()
+    pp = ctx.pairing_pairs([R(_A), L(_A), R(_W1), R(_W2), L(_W1), L(_W2)], [L(_V1), L(_V2), L(_B), R(_V1), R(_V2), R(_B)],
+                           [(0, 0), (2, 2), (0, 1), (3, 2), (0, 2), (1, 3), (4, 5), (1, 4), (5, 5), (1, 5)], h)
+    t1 = time.perf_counter()
+    D = F.decode
+    TL = F.mul(D(pp[0]), D(pp[1])); UL = F.mul(D(pp[2]), D(pp[3])); ZL = D(pp[4])
+    TR = F.mul(D(pp[5]), D(pp[6])); UR = F.mul(D(pp[7]), D(pp[8])); ZR = D(pp[9])
+    tr.absorb(b"round", *(F.encode(x) for x in (TL, UL, ZL, TR, UR, ZR)))
+    c = tr.challenge(b"c")
+    rounds.append(dict(TL=TL, UL=UL, ZL=ZL, TR=TR, UR=UR, ZR=ZR))
+    challenges.append(c)
+    t2 = time.perf_counter()
+    nxt = _fold(ctx, go, win, pos, m, c, pow(c, -1, r))
+    times.append((m, t1 - t0, t2 - t1, time.perf_counter() - t2))
+    return nxt
+
+
+def _round_pair(ctx, F, fc, r, win, pos, m, tr, go, rounds, challenges, times):
+    """Two rounds for one pass through the pairing pipeline: the messages of round k + 1 are inner products of the FOLDED
+    vectors, and by bilinearity those are products of quarter-by-quarter inner products of the current vectors raised to
+    1, c, 1 / c - so the sixty quarter products both rounds need are taken in ONE batched call (one lines / tree / Horner
+    chain instead of two), round k's messages are products of them, and round k + 1's one grouped multi-exponentiation
+    that runs beside round k's fold.  The messages are the same GT elements, bit for bit, as round by round."""
+    q = m // 4
+    t0 = time.perf_counter()
+    quarter = lambda k, i: win(k, pos + i * q, q)
+    lhs = [quarter(k, i) for k in _G1_VECS for i in range(4)]
+    rhs = [quarter(k, j) for k in _G2_VECS for j in range(4)]
+    pairs = [(4 * _G1_VECS.index(x) + i, 4 * _G2_VECS.index(y) + j) for x, y in _NAME_PAIRS for i, j in _QUARTERS]
+    E = np.asarray(ctx.pairing_pairs(lhs, rhs, pairs, q), np.uint8).reshape(len(pairs), -1)
+    t1 = time.perf_counter()
+    e = lambda p, i, j: E[len(_QUARTERS) * p + _Q[(i, j)]]
+    one = np.frombuffer(F.encode(F.one), np.uint8)
+
+    def messages(factors_of, c, c_inv):
+        """(TL, UL, ZL, TR, UR, ZR) as ONE grouped multi-exponentiation: factors_of(side) lists ((i, j), exponent) per name pair."""
+        bases, exps = [], []
+        for side in "LR":
+            for _name, members in _MESSAGES:
+                for p in members:
+                    for (i, j), k in factors_of(side, c, c_inv):
+                        bases.append(e(p, i, j)); exps.append(k)
+                for _pad in range((2 - len(members)) * len(factors_of(side, c, c_inv))):
+                    bases.append(one); exps.append(0)
+        glen = len(bases) // 6
+        out = ctx.gt_pow_prod(np.concatenate(bases), fc.enc(exps), glen)
+        return [F.decode(out[g]) for g in range(6)]
+
+    def absorb(msgs):
+        TL, UL, ZL, TR, UR, ZR = msgs
+        tr.absorb(b"round", *(F.encode(x) for x in msgs))
+        c = tr.challenge(b"c")
+        rounds.append(dict(TL=TL, UL=UL, ZL=ZL, TR=TR, UR=UR, ZR=ZR))
+        challenges.append(c)
+        return c, pow(c, -1, r)
+
+    now = lambda side, c, ci: ((((2, 0), 1), ((3, 1), 1)) if side == "L" else (((0, 2), 1), ((1, 3), 1)))
+    nxt_round = lambda side, c, ci: ((((1, 0), 1), ((1, 2), ci), ((3, 0), c), ((3, 2), 1)) if side == "L" else
+                                     (((0, 1), 1), ((0, 3), ci), ((2, 1), c), ((2, 3), 1)))
+    c, c_inv = absorb(messages(now, 1, 1))
+    t2 = time.perf_counter()
+    f_next = go(messages, nxt_round, c, c_inv)                    # round k + 1's messages, beside round k's fold
+    pos1 = _fold(ctx, go, win, pos, m, c, c_inv)
+    t3 = time.perf_counter()
+    c2, c2_inv = absorb(f_next.result())
+    t4 = time.perf_counter()
+    pos2 = _fold(ctx, go, win, pos1, m // 2, c2, c2_inv)
+    times.append((m, t1 - t0, t2 - t1, t3 - t2))
+    times.append((m // 2, 0.0, t4 - t3, time.perf_counter() - t4))
+    return pos2
+
+
+def gipa_rounds(ctx, F, fc, r, win, n, tr, go, rounds, challenges, times, paired=True):
+    """The log2(n) rounds of the recursion over the six device-resident vectors `win(k, start, count)` addresses; appends
+    the rounds' messages and challenges, returns the position of the final single elements."""
+    m, pos = n, 0
+    while m > 1:
+        if paired and m >= 4:
+            pos = _round_pair(ctx, F, fc, r, win, pos, m, tr, go, rounds, challenges, times)
+            m //= 4
+        else:
+            pos = _single_round(ctx, F, r, win, pos, m, tr, go, rounds, challenges, times)
+            m //= 2
+    return pos
+
+
 class Tipp:
     def __init__(self, ctx, curve):
         self.ctx, self.curve = ctx, curve
@@ -187,38 +308,9 @@ class Tipp:
         tr.absorb(b"instance", F.encode(com.t), F.encode(com.u), F.encode(z_ab), twist.to_bytes(32, "little"), n.to_bytes(8, "little"))
         rounds, challenges = [], []
         self.round_times = []                                               # (m, pairings s, host s, folds s) per round
-        m, pos = n, 0                                                       # the current vectors start at element `pos`
         t_rounds = time.perf_counter()
-        while m > 1:
-            h = m // 2
-            L = lambda k: win(k, pos, h)
-            R = lambda k: win(k, pos + h, h)
-            aL, aR, bL, bR = L(0), R(0), L(1), R(1)
-            v1L, v1R, v2L, v2R = L(2), R(2), L(3), R(3)
-            w1L, w1R, w2L, w2R = L(4), R(4), L(5), R(5)
-            # all ten multi-pairings of the round in ONE batched call: ten (lhs, rhs) pairs out of 6 x 6, every G2 vector's
-            # Miller lines computed once
-            t0 = time.perf_counter()
-            pp = ctx.pairing_pairs([aR, aL, w1R, w2R, w1L, w2L], [v1L, v2L, bL, v1R, v2R, bR],
-                                   [(0, 0), (2, 2), (0, 1), (3, 2), (0, 2), (1, 3), (4, 5), (1, 4), (5, 5), (1, 5)], h)
-            t1 = time.perf_counter()
-            D = F.decode
-            TL = F.mul(D(pp[0]), D(pp[1])); UL = F.mul(D(pp[2]), D(pp[3])); ZL = D(pp[4])
-            TR = F.mul(D(pp[5]), D(pp[6])); UR = F.mul(D(pp[7]), D(pp[8])); ZR = D(pp[9])
-            tr.absorb(b"round", *(F.encode(x) for x in (TL, UL, ZL, TR, UR, ZR)))
-            c = tr.challenge(b"c")
-            c_inv = pow(c, -1, r)
-            rounds.append(dict(TL=TL, UL=UL, ZL=ZL, TR=TR, UR=UR, ZR=ZR))
-            challenges.append(c)
-            nxt = pos + m                                                   # the folds go right behind the current vectors
-            t2 = time.perf_counter()
-            # the three G1 folds share c, the three G2 folds c^-1: one batched call per group, issued together
-            # (the G2 fold is the longer one: it goes out from this thread, the G1 fold beside it from the pool)
-            g1_fold = go(ctx.points_fold_many, 1, [aL, w1L, w2L], [aR, w1R, w2R], c, h, [win(k, nxt, h) for k in (0, 4, 5)])
-            ctx.points_fold_many(2, [bL, v1L, v2L], [bR, v1R, v2R], c_inv, h, [win(k, nxt, h) for k in (1, 2, 3)])
-            g1_fold.result()
-            self.round_times.append((m, t1 - t0, t2 - t1, time.perf_counter() - t2))
-            m, pos = h, nxt
+        paired = not os.environ.get("HK_TIPP_SINGLE_ROUNDS")
+        pos = gipa_rounds(ctx, F, fc, r, win, n, tr, go, rounds, challenges, self.round_times, paired)
         t_open = time.perf_counter()
         a, b, v1, v2, w1, w2 = (win(k, pos, 1).to_host() for k in range(6))
         arena.free()

@@ -52,6 +52,17 @@ def test_tipp_closes_the_aggregation_of_real_proofs(cname, ctx_bn254, ctx_bls):
     vk = tipa.verifier_key(ctx, cname, srs)
     assert T.verify(vk, inst["commitment"], inst["output"], twist, proof)
     assert len(proof["rounds"]) == 3
+    # rounds are taken two per pass through the pairing pipeline (tipa._round_pair: quarter-by-quarter inner products,
+    # round k + 1's messages by bilinearity); round by round the prover sends the same proof, member for member
+    import os
+    os.environ["HK_TIPP_SINGLE_ROUNDS"] = "1"
+    try:
+        single = T.prove(srs, inst["left"], inst["right"], twist, inst["commitment"], inst["output"])
+    finally:
+        del os.environ["HK_TIPP_SINGLE_ROUNDS"]
+    assert single["rounds"] == proof["rounds"]
+    for key in ("final_a", "final_b", "final_v", "final_w", "open_v", "open_w"):
+        assert np.array_equal(np.asarray(single[key]), np.asarray(proof[key])), key
 
     # ---- the folded keys are the closed-form images of the SRS: v' = f_v(alpha) h, w' = f_w(alpha) g
     F = T.F
