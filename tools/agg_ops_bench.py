@@ -97,6 +97,7 @@ def main():
         assert ok
         print("%-8s %8d %14.1f %14.1f %14.1f" % (curve, n, t_setup * 1e3, t_prove * 1e3, t_verify * 1e3))
         print("         prove: setup %.1f ms, rounds %.1f ms, openings %.1f ms" % tuple(x * 1e3 for x in T.phase_times))
+        # (rounds go two per pairing pass: the second of a pair shows 0.0 ms of pairings)
         print("         rounds (m: pairings / host / folds ms): " + "  ".join(
             "%d: %.1f/%.1f/%.1f" % (m, a * 1e3, b * 1e3, c * 1e3) for m, a, b, c in T.round_times))
         for rb in srs.resident.values():
