@@ -99,3 +99,18 @@ def test_paired_rounds_send_the_messages_of_the_round_by_round_form(n):
         pos, m = pos + m, m // 2
         assert T == (sum(x * y for x, y in zip(a[pos:pos + m], v1[pos:pos + m])) +
                      sum(x * y for x, y in zip(w1[pos:pos + m], b[pos:pos + m]))) % R_MOD
+
+
+def test_a_round_pair_fits_the_batched_pairing_call():
+    """One pass takes 5 vector pairs x 12 quarter combinations = 60 pairs out of 12 + 12 quarter vectors: inside the pair
+    list hk_pairing_pairs accepts (PAIR_LIST_MAX) and the row table of its gather launch (GatherRows::MAX)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hekaton_system_amd", "csrc")
+    drv = open(os.path.join(root, "msm_driver.cuh")).read()
+    impl = open(os.path.join(root, "prove_impl.cuh")).read()
+    pair_max = int(re.search(r"PAIR_LIST_MAX\s*=\s*(\d+)", drv).group(1))
+    rows_max = int(re.search(r"struct GatherRows \{\s*enum \{ MAX = (\d+) \}", impl).group(1))
+    assert len(tipa._NAME_PAIRS) * len(tipa._QUARTERS) == 60 <= pair_max
+    assert 4 * (len(tipa._G1_VECS) + len(tipa._G2_VECS)) == 24 <= rows_max
+    assert len(set(tipa._QUARTERS)) == 12 and all(0 <= i < 4 and 0 <= j < 4 for i, j in tipa._QUARTERS)
