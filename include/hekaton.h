@@ -181,7 +181,10 @@ hk_status hk_pairing_products(hk_ctx* ctx, const void* const* lhs_g1, size_t n_l
  * gt_out[p] = pairing(lhs_g1[pair_lhs[p]], rhs_g2[pair_rhs[p]]), p < n_pairs <= 64.  One GIPA round of the TIPA prover
  * (ark-ip-proofs `gipa` under distributed-prover/src/aggregation.rs:340) needs ten inner products between six G1 and six
  * G2 half-vectors - e(A_R, v1_L), e(w1_R, B_L), ... - each rhs vector's Miller lines are computed once and shared by the
- * pairs that use it.  pair_lhs, pair_rhs [h]: n_pairs indices into lhs_g1 / rhs_g2. */
+ * pairs that use it.  pair_lhs, pair_rhs [h]: n_pairs indices into lhs_g1 / rhs_g2 (at most 64 pairs).  TWO rounds fit one
+ * call: round k + 1's messages are inner products of the folded vectors, by bilinearity products of quarter-by-quarter
+ * inner products of the current vectors raised to 1, c, 1 / c - sixty pairs out of twelve G1 and twelve G2 quarter
+ * vectors, then hk_gt_pow_prod (hekaton_system_amd/tipa.py `_round_pair`). */
 hk_status hk_pairing_pairs(hk_ctx* ctx, const void* const* lhs_g1, size_t n_lhs, const void* const* rhs_g2, size_t n_rhs,
                            const uint32_t* pair_lhs, const uint32_t* pair_rhs, size_t n_pairs, size_t n, void* gt_out);
 hk_status hk_ctx_gt_bytes(const hk_ctx* ctx, size_t* gt);
